@@ -1,0 +1,131 @@
+// fa_api.hip -- the C-ABI entry points of include/fa_mi355.h.
+// Validation + dispatch only; every kernel lives in its own file.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fa_common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+}  // namespace
+
+extern "C" {
+
+const char *fa_last_error(void) { return g_err; }
+int fa_version(void) { return FA_MI355_VERSION; }
+
+const char *fa_variant_name(int v) {
+  switch (v) {
+    case FA_VARIANT_AUTO: return "auto";
+    case FA_VARIANT_NAIVE: return "naive";
+    case FA_VARIANT_TILED: return "tiled";
+    case FA_VARIANT_TILED_V2: return "tiled_v2";
+    case FA_VARIANT_MFMA: return "mfma";
+    default: return "?";
+  }
+}
+const char *fa_dtype_name(int d) {
+  switch (d) {
+    case FA_DTYPE_F32: return "f32";
+    case FA_DTYPE_F16: return "f16";
+    case FA_DTYPE_BF16: return "bf16";
+    case FA_DTYPE_FP8_E4M3: return "fp8_e4m3";
+    default: return "?";
+  }
+}
+int fa_dtype_in_bytes(int d) {
+  switch (d) {
+    case FA_DTYPE_F32: return 4;
+    case FA_DTYPE_F16: case FA_DTYPE_BF16: return 2;
+    case FA_DTYPE_FP8_E4M3: return 1;
+    default: return 0;
+  }
+}
+int fa_dtype_out_bytes(int d) { return d == FA_DTYPE_FP8_E4M3 ? 2 : fa_dtype_in_bytes(d); }
+
+int fa_supported(int dtype, int variant, int D) {
+  switch (variant) {
+    case FA_VARIANT_AUTO: return fa_resolve_variant(dtype, D) > 0;
+    case FA_VARIANT_NAIVE: return fa::naive_supported(dtype, D);
+    case FA_VARIANT_TILED: return fa::tiled_supported(dtype, D);
+    case FA_VARIANT_TILED_V2: return fa::tiled_v2_supported(dtype, D);
+    case FA_VARIANT_MFMA: return fa::mfma_supported(dtype, D);
+    default: return 0;
+  }
+}
+int fa_resolve_variant(int dtype, int D) {
+  if (fa::mfma_supported(dtype, D)) return FA_VARIANT_MFMA;
+  if (fa::tiled_v2_supported(dtype, D)) return FA_VARIANT_TILED_V2;
+  return FA_ERR_UNSUPPORTED;
+}
+
+double fa_algorithmic_flops(int B, int H, int N, int D, int is_causal) {
+  return (is_causal ? 2.0 : 4.0) * (double)B * H * (double)N * (double)N * D;
+}
+double fa_algorithmic_bytes(int B, int H, int N, int D, int dtype) {
+  return (3.0 * fa_dtype_in_bytes(dtype) + fa_dtype_out_bytes(dtype)) * (double)B * H * N * D +
+         4.0 * (double)B * H * N;
+}
+
+int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int B, int H, int N,
+           int D, float scale, long long batch_stride, long long head_stride, int is_causal,
+           int dtype, int variant, void *hip_stream) {
+  g_err[0] = 0;
+  if (!q || !k || !v || !o) return fail(FA_ERR_INVALID_ARG, "fa_fwd: null tensor pointer");
+  if (B < 1 || H < 1 || N < 1 || D < 1)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: B=%d H=%d N=%d D=%d must be >= 1", B, H, N, D);
+  if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "fa_fwd: scale=%g must be > 0", (double)scale);
+  if (fa_dtype_in_bytes(dtype) == 0) return fail(FA_ERR_INVALID_ARG, "fa_fwd: bad dtype %d", dtype);
+  if (head_stride < (long long)N * D || batch_stride < 0 || (H > 1 && batch_stride < head_stride))
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: strides (batch %lld, head %lld) smaller than a head (N*D=%lld)",
+                batch_stride, head_stride, (long long)N * D);
+  if ((batch_stride % 8) || (head_stride % 8))
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: strides must be multiples of 8 elements");
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: tensors must be 16-byte aligned");
+  if ((double)N * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: one head exceeds 4 GiB");
+  if ((long long)B * H > 0x7fffffffLL / ((N + 127) / 128))
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: grid too large");
+  if (variant == FA_VARIANT_AUTO) {
+    variant = fa_resolve_variant(dtype, D);
+    if (variant < 0)
+      return fail(FA_ERR_UNSUPPORTED, "fa_fwd: no kernel for dtype=%s D=%d", fa_dtype_name(dtype), D);
+  }
+  if (!fa_supported(dtype, variant, D))
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd: variant=%s does not support dtype=%s D=%d",
+                fa_variant_name(variant), fa_dtype_name(dtype), D);
+  if ((variant == FA_VARIANT_NAIVE || variant == FA_VARIANT_TILED || variant == FA_VARIANT_TILED_V2) &&
+      (H > 65535 || B > 65535))
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: B,H must be <= 65535 for variant %s", fa_variant_name(variant));
+
+  fa::Params p;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
+  p.B = B; p.H = H; p.N = N; p.D = D;
+  p.scale = scale;
+  p.batch_stride = batch_stride; p.head_stride = head_stride;
+  p.is_causal = is_causal ? 1 : 0;
+  hipStream_t s = (hipStream_t)hip_stream;
+  hipError_t e;
+  switch (variant) {
+    case FA_VARIANT_NAIVE: e = fa::launch_naive(p, dtype, s); break;
+    case FA_VARIANT_TILED: e = fa::launch_tiled(p, dtype, s); break;
+    case FA_VARIANT_TILED_V2: e = fa::launch_tiled_v2(p, dtype, s); break;
+    default: e = fa::launch_mfma(p, dtype, s); break;
+  }
+  if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)
+    return fail(FA_ERR_NO_DEVICE, "fa_fwd: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_fwd: launch failed: %s", hipGetErrorString(e));
+  return FA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// fa_common.h -- internal declarations shared by the gfx950 kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fa_mi355.h"
+
+namespace fa {
+
+// One launch of the operator (mirror of the binding table kernels.metal:600-613).
+struct Params {
+  const void *q, *k, *v;
+  void *o;
+  float *lse;  // nullable
+  int B, H, N, D;
+  float scale;
+  long long batch_stride, head_stride;  // elements
+  int is_causal;
+};
+
+// dtype tags
+struct F32 {};
+struct F16 {};
+struct BF16 {};
+struct FP8 {};
+
+// launchers: return hipError_t of the launch
+hipError_t launch_naive(const Params &p, int dtype, hipStream_t s);
+hipError_t launch_tiled(const Params &p, int dtype, hipStream_t s);
+hipError_t launch_tiled_v2(const Params &p, int dtype, hipStream_t s);
+hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s);
+
+bool naive_supported(int dtype, int D);
+bool tiled_supported(int dtype, int D);
+bool tiled_v2_supported(int dtype, int D);
+bool mfma_supported(int dtype, int D);
+
+// ---- element load/store helpers for the scalar kernels -------------------
+__device__ __forceinline__ float ld_elem(const float *p, long long i) { return p[i]; }
+__device__ __forceinline__ float ld_elem(const _Float16 *p, long long i) { return (float)p[i]; }
+__device__ __forceinline__ float ld_elem(const __bf16 *p, long long i) { return (float)p[i]; }
+__device__ __forceinline__ void st_elem(float *p, long long i, float v) { p[i] = v; }
+__device__ __forceinline__ void st_elem(_Float16 *p, long long i, float v) { p[i] = (_Float16)v; }
+__device__ __forceinline__ void st_elem(__bf16 *p, long long i, float v) { p[i] = (__bf16)v; }
+
+}  // namespace fa

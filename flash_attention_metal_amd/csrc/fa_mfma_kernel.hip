@@ -1,0 +1,362 @@
+// fa_mfma_kernel.hip -- the operator on the CDNA4 matrix cores.
+//
+// Replaces /root/reference/kernels.metal:600-883 (flash_attention_v4_half_kernel)
+// and :177-455 (flash_attention_simd_kernel): same math -- tiled QK^T ->
+// online softmax -> PV, causal predicate `key > query -> masked`
+// (kernels.metal:748), whole-tile skip (kernels.metal:682), L = m + ln(l)
+// (kernels.metal:862-864) -- nothing else is shared with it. fp32 accumulators
+// for S, O, m, l (the reference accumulates S and O in half).
+//
+// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head)):
+//   * each wave owns 32 query rows; its Q fragments stay in registers
+//   * K/V tiles of 64 keys are double-buffered in LDS: the next tile's
+//     128-bit buffer loads are issued before the current tile's arithmetic and
+//     written to the other buffer after it; one barrier per tile
+//   * S^T = K.Q^T with v_mfma_f32_32x32x16 ("swapped" product): the query index
+//     lands on the lane, the 32 key scores of a block in that lane's 16
+//     accumulator registers (+16 in lane^32), so row max / row sum are
+//     in-register reductions plus ONE v_permlane32_swap -- no LDS round trip
+//   * P^T feeds the PV product straight from those registers as the B operand
+//     (k order inside a step is the accumulator's row order; V^T is read from
+//     LDS in the same order with ds_read_b64_tr_b16, so V stays row-major)
+//   * O^T accumulates in 16*(D/32) registers; the O rescale is skipped when no
+//     row max in the wave moved (exact: alpha == 1)
+//   * K rows are XOR-swizzled in LDS for conflict-free ds_read_b128, V rows for
+//     conflict-free transposed reads
+//   * epilogue: O tile -> LDS -> whole 128-byte rows, 16 B per lane
+//   * grid: 1-D, heads dealt to XCDs (blocks b and b+8 share an L2) so one
+//     head's K/V stays in one L2; causal q-blocks heaviest first
+#include "fa_common.h"
+
+namespace fa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename Tag> struct MT;
+template <> struct MT<BF16> {
+  using elem = __bf16;
+  using vec8 = bf16x8;
+  __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MT<F16> {
+  using elem = _Float16;
+  using vec8 = f16x8;
+  __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int BM = 128;      // query rows per workgroup
+constexpr int WM = 32;       // query rows per wave
+constexpr int BN = 64;       // keys per tile
+constexpr int NTHREADS = 256;
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+__device__ __forceinline__ u32x4 lds_read_b128(const lds_char *p) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(p);
+}
+__device__ __forceinline__ void lds_write_b128(lds_char *p, u32x4 v) {
+  *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(p) = v;
+}
+__device__ __forceinline__ void lds_write_b64(lds_char *p, u32x2 v) {
+  *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(p) = v;
+}
+// transposed 4x16 block read (ds_read_b64_tr_b16): lane i of a 16-lane group
+// receives column i of the 4 rows whose addresses lanes 4q+p supplied
+__device__ __forceinline__ s16x4 lds_read_tr16(const lds_char *p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(p));
+}
+
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
+  using M = MT<Tag>;
+  using vec8 = typename M::vec8;
+  using elem = typename M::elem;
+  constexpr int RB = D * 2;                 // row bytes
+  constexpr int CPR = D / 8;                // 16-byte chunks per row
+  constexpr int KS = D / 16;                // k-steps of the QK^T product
+  constexpr int DB = D / 32;                // 32-wide d blocks of O^T
+  constexpr int TILE = BN * RB;             // bytes of one K (or V) tile
+  constexpr int NCH = BN * CPR / NTHREADS;  // staged chunks per thread per tile
+
+  extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+  lds_char *smem = (lds_char *)smem_generic;
+  lds_char *Kbuf = smem;             // [2][BN][RB], rows swizzled
+  lds_char *Vbuf = smem + 2 * TILE;  // [2][BN][RB], rows swizzled
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;  // query within the wave / key row within a block
+  const int h = lane >> 5;  // lane half
+
+  // ---- block -> (batch*head, q block). blocks b and b+8 share an XCD's L2:
+  // deal heads to the 8 residues so a head's K/V stays in one L2.
+  const int nQ = (p.N + BM - 1) / BM;
+  const int BH = p.B * p.H;
+  int bh, qb;
+  {
+    const int id = blockIdx.x;
+    const int full = (BH / 8) * 8;  // heads that can be dealt 8 at a time
+    if (id < full * nQ) {
+      const int xcd = id & 7, slot = id >> 3;
+      bh = (slot / nQ) * 8 + xcd;
+      qb = slot % nQ;
+    } else {
+      const int rem = id - full * nQ;
+      bh = full + rem / nQ;
+      qb = rem % nQ;
+    }
+    if (CAUSAL) qb = nQ - 1 - qb;  // heaviest q blocks first
+  }
+  const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
+  const int q0 = qb * BM;
+  const int qw0 = q0 + wave * WM;  // first query row of this wave
+  const int qrow = qw0 + r;
+
+  const unsigned head_bytes = (unsigned)p.N * RB;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)((const elem *)p.q + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)((const elem *)p.k + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)((const elem *)p.v + base), 0, head_bytes, 0x00020000);
+
+  // ---- Q fragments (B operand of K.Q^T): lane (r,h) holds Q[qrow][16ks+8h .. +7].
+  // Rows >= N read as zero through the descriptor's range check.
+  vec8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + (2 * ks + h) * 16, 0, 0);
+    qf[ks] = __builtin_bit_cast(vec8, t);
+  }
+
+  // ---- per-lane LDS offsets
+  // K: ds_read_b128 of row (32kb + r), chunk (2ks + h); swizzle depends on r only
+  const int kx = (D == 64) ? ((r >> 1) & 7) : (r & 15);
+  int koff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) koff[ks] = r * RB + (((2 * ks + h) ^ kx) << 4);
+  // V: transposed read; 16-lane group g covers d columns 16(g&1).. of block db,
+  // lane 4q+pp of the group addresses row (.. + 4h + q), columns 4pp..4pp+3
+  const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
+  const int vx = (D == 64) ? (((vq >> 1) & 1) << 2) : (vq << 2);
+  int voff[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+    voff[db] = (4 * h + vq) * RB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
+
+  // ---- staging: thread -> NCH 16-byte chunks of the K tile and of the V tile
+  int st_g[NCH], st_k[NCH], st_v[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NTHREADS;
+    const int row = c / CPR, ch = c % CPR;
+    st_g[i] = row * RB + ch * 16;
+    const int skx = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    const int svx = (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+    st_k[i] = row * RB + ((ch ^ skx) << 4);
+    st_v[i] = row * RB + ((ch ^ svx) << 4);
+  }
+
+  const int kv_end = CAUSAL ? min(p.N, q0 + BM) : p.N;
+  const int nT = (kv_end + BN - 1) / BN;
+
+  u32x4 kst[NCH], vst[NCH];
+  auto stage_load = [&](int t) {
+    const unsigned g0 = (unsigned)t * TILE;  // tile t starts at key t*BN
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, g0 + st_g[i], 0, 0);
+      vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, g0 + st_g[i], 0, 0);
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      lds_write_b128(Kbuf + buf * TILE + st_k[i], kst[i]);
+      lds_write_b128(Vbuf + buf * TILE + st_v[i], vst[i]);
+    }
+  };
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[db][i] = 0.0f;
+  float m = -INFINITY;  // running max of the raw (unscaled) scores of this row
+  float l = 0.0f;       // this lane half's share of the running sum
+  const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
+
+  stage_load(0);
+  stage_write(0);
+  __syncthreads();
+
+  for (int t = 0; t < nT; ++t) {
+    const int buf = t & 1;
+    const int kv0 = t * BN;
+    if (t + 1 < nT) stage_load(t + 1);  // in flight under this tile's MFMAs
+
+    // whole-tile skip per wave (kernels.metal:682 with Br = 32): every key of
+    // the tile is past this wave's last query row
+    const bool wave_active = !CAUSAL || (kv0 <= qw0 + WM - 1);
+    if (wave_active) {
+      const lds_char *Kt = Kbuf + buf * TILE;
+      const lds_char *Vt = Vbuf + buf * TILE;
+      // ---- S^T = K.Q^T : s[kb][reg] = S[q = r][key = kv0 + 32kb + (reg&3) + 8(reg>>2) + 4h]
+      f32x16 s[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const vec8 a = __builtin_bit_cast(vec8, lds_read_b128(Kt + kb * 32 * RB + koff[ks]));
+          s[kb] = M::mfma(a, qf[ks], s[kb]);
+        }
+      }
+      // ---- mask (only on tiles that cross the diagonal or the end of the sequence)
+      const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0)) || (kv0 + BN > p.N);
+      if (need_mask) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          // masked iff key > qrow (kernels.metal:748) or key >= N
+          int lim = p.N - 1 - kv0 - 32 * kb - 4 * h;
+          if (CAUSAL) lim = min(lim, qrow - kv0 - 32 * kb - 4 * h);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int kpart = (i & 3) + 8 * (i >> 2);
+            s[kb][i] = (kpart > lim) ? -INFINITY : s[kb][i];
+          }
+        }
+      }
+      // ---- online softmax, lane-local + one half swap
+      float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s[0][i], s[1][i]));
+      {
+        const unsigned u = __builtin_bit_cast(unsigned, mx);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+      }
+      const float m_new = fmaxf(m, mx);
+      if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {  // wave-uniform; exact skip when no max moved
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c2);
+        l *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+        m = m_new;
+      }
+      const float mc = m * c2;
+      float ls0 = 0.0f, ls1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc));
+        s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mc));
+        ls0 += s[0][i];
+        ls1 += s[1][i];
+      }
+      l += ls0 + ls1;
+      // ---- O^T += V^T.P^T : per 16-key step, P fragment = 8 accumulator registers
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          vec8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = (elem)s[kb][8 * st + j];
+#pragma unroll
+          for (int db = 0; db < DB; ++db) {
+            const lds_char *vb = Vt + (32 * kb + 16 * st) * RB + voff[db];
+            const s16x4 lo = lds_read_tr16(vb);           // keys +4h+0..3   (k elements 0..3)
+            const s16x4 hi = lds_read_tr16(vb + 8 * RB);  // keys +8+4h+0..3 (k elements 4..7)
+            const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            oacc[db] = M::mfma(__builtin_bit_cast(vec8, v8), pf, oacc[db]);
+          }
+        }
+      }
+    }
+    if (t + 1 < nT) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, LSE, O tile -> LDS -> coalesced 16-byte stores
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, l);
+    auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    l = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
+  }
+  const float inv_l = 1.0f / l;
+  if (p.lse != nullptr && h == 0 && qrow < p.N)
+    p.lse[(long long)bh * p.N + qrow] = m * p.scale + logf(l);
+
+  lds_char *Ot = smem + wave * (WM * RB);  // this wave's [32][D] tile (inside the K buffers)
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      // registers 4g4..4g4+3 = d columns 32db + 8g4 + 4h + 0..3 of row r
+      elem e0 = (elem)(oacc[db][4 * g4 + 0] * inv_l), e1 = (elem)(oacc[db][4 * g4 + 1] * inv_l);
+      elem e2 = (elem)(oacc[db][4 * g4 + 2] * inv_l), e3 = (elem)(oacc[db][4 * g4 + 3] * inv_l);
+      u32x2 w;
+      w[0] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+      w[1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+      // 16-byte chunk index XOR (r & (CPR-1)) spreads the rows over the banks
+      const int col_b = (32 * db + 8 * g4 + 4 * h) * 2;
+      const int ch = (col_b >> 4) ^ (r & (CPR - 1));
+      lds_write_b64(Ot + r * RB + (ch << 4) + (col_b & 15), w);
+    }
+  }
+  __syncthreads();
+  elem *Og = (elem *)p.o + base;
+#pragma unroll
+  for (int it = 0; it < WM * CPR / 64; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / CPR, ch = idx % CPR;
+    const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPR - 1))) << 4));
+    if (qw0 + row < p.N)
+      *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
+  }
+}
+
+// ---------------------------------------------------------------------------
+bool mfma_supported(int dtype, int D) {
+  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128);
+}
+
+template <typename Tag, int D, bool CAUSAL>
+static hipError_t launch_one(const Params &p, hipStream_t s) {
+  const int nQ = (p.N + BM - 1) / BM;
+  const size_t smem = 4 * BN * D * 2;
+  auto kern = fwd_mfma_kernel<Tag, D, CAUSAL>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, p);
+  return hipGetLastError();
+}
+
+template <typename Tag>
+static hipError_t launch_dt(const Params &p, hipStream_t s) {
+  if (p.D == 64) return p.is_causal ? launch_one<Tag, 64, true>(p, s) : launch_one<Tag, 64, false>(p, s);
+  return p.is_causal ? launch_one<Tag, 128, true>(p, s) : launch_one<Tag, 128, false>(p, s);
+}
+
+hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s) {
+  return dtype == FA_DTYPE_F16 ? launch_dt<F16>(p, s) : launch_dt<BF16>(p, s);
+}
+
+}  // namespace fa

@@ -1,0 +1,102 @@
+"""The operator: flash_attention_forward(Q, K, V, is_causal) -> (O, LSE).
+
+Argument meaning follows the reference binding table
+(/root/reference/kernels.metal:600-613, host side /root/reference/main.mm:821-852):
+tensors are ``[B, H, N, D]`` with rows contiguous; batch/head strides are taken
+from the tensors; ``scale`` defaults to ``1/sqrt(D)`` (main.mm:13); ``lse`` is
+``[B, H, N]`` fp32 (kernels.metal:611). Errors follow the C-ABI: a negative
+status becomes :class:`FaError` carrying ``fa_last_error()``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from ._lib import load_library
+
+DTYPES = {"f32": 0, "f16": 1, "bf16": 2, "fp8_e4m3": 3}
+VARIANTS = {"auto": 0, "naive": 1, "tiled": 2, "tiled_v2": 3, "mfma": 4}
+
+_TORCH2FA = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+if hasattr(torch, "float8_e4m3fn"):
+    _TORCH2FA[torch.float8_e4m3fn] = 3
+
+
+class FaError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"fa_fwd failed ({status}): {msg}")
+        self.status = status
+
+
+def supported(dtype: str, variant: str, D: int) -> bool:
+    return bool(load_library().fa_supported(DTYPES[dtype], VARIANTS[variant], D))
+
+
+def algorithmic_flops(B: int, H: int, N: int, D: int, is_causal: bool) -> float:
+    return float(load_library().fa_algorithmic_flops(B, H, N, D, int(is_causal)))
+
+
+def algorithmic_bytes(B: int, H: int, N: int, D: int, dtype: str) -> float:
+    return float(load_library().fa_algorithmic_bytes(B, H, N, D, DTYPES[dtype]))
+
+
+def _strides(t: torch.Tensor) -> Tuple[int, int]:
+    """(batch_stride, head_stride) in elements; size-1 dims get the dense value."""
+    B, H, N, D = t.shape
+    sb, sh, sn, sd = t.stride()
+    if sd != 1 or sn != D:
+        raise ValueError("rows must be contiguous with pitch D (kernels.metal:622: offset = b*bs + h*hs)")
+    hs = sh if H > 1 else N * D
+    bs = sb if B > 1 else H * hs
+    return bs, hs
+
+
+def flash_attention_forward(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    is_causal: bool = False,
+    scale: Optional[float] = None,
+    variant: str = "auto",
+    return_lse: bool = True,
+    out: Optional[torch.Tensor] = None,
+    lse: Optional[torch.Tensor] = None,
+    stream: Optional[int] = None,
+) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Launch the gfx950 kernel on the current torch stream (asynchronous)."""
+    lib = load_library()
+    if q.dim() != 4 or q.shape != k.shape or q.shape != v.shape:
+        raise ValueError(f"q, k, v must share one [B,H,N,D] shape, got {tuple(q.shape)} {tuple(k.shape)} {tuple(v.shape)}")
+    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+        raise RuntimeError("flash_attention_forward needs device tensors: there is no CPU path "
+                           "(the CPU oracle lives in oracle/ and is test infrastructure only)")
+    if q.dtype not in _TORCH2FA or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError(f"unsupported / mixed dtypes {q.dtype} {k.dtype} {v.dtype}")
+    B, H, N, D = q.shape
+    bs, hs = _strides(q)
+    if _strides(k) != (bs, hs) or _strides(v) != (bs, hs):
+        raise ValueError("q, k, v must share batch/head strides (one stride pair in the binding table)")
+    fa_dtype = _TORCH2FA[q.dtype]
+    out_dtype = torch.bfloat16 if fa_dtype == 3 else q.dtype
+    if out is None:
+        out = torch.empty_strided((B, H, N, D), q.stride(), dtype=out_dtype, device=q.device)
+    elif out.dtype != out_dtype or out.shape != q.shape or _strides(out) != (bs, hs):
+        raise ValueError("out must match q's shape/strides (and be bf16 for fp8 inputs)")
+    if return_lse and lse is None:
+        lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
+    if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != B * H * N):
+        raise ValueError("lse must be contiguous fp32 [B,H,N]")
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if stream is None:
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+    with torch.cuda.device(q.device):
+        st = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                        lse.data_ptr() if lse is not None else None,
+                        B, H, N, D, float(scale), bs, hs, int(bool(is_causal)),
+                        fa_dtype, VARIANTS[variant], stream)
+    if st != 0:
+        raise FaError(st, lib.fa_last_error().decode())
+    return out, lse

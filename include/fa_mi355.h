@@ -1,0 +1,113 @@
+/*
+ * fa_mi355.h -- C-ABI of the MI355X (gfx950) attention-forward kernel library.
+ *
+ * This is the drop-in boundary for the reference's one operator,
+ *     (Q, K, V, is_causal) -> O (+ LSE)
+ * The reference has no FFI: its operator interface is the Metal binding table
+ * of flash_attention_v4_half_kernel (/root/reference/kernels.metal:600-613) as
+ * bound by the host at /root/reference/main.mm:821-852. fa_fwd() replaces that
+ * table one argument for one slot:
+ *
+ *   buffer 0-2  Q,K,V  kernels.metal:601-603 / main.mm:822-824  -> q, k, v
+ *   buffer 3    O      kernels.metal:604     / main.mm:825      -> o
+ *   bytes  4    N      kernels.metal:605     / main.mm:826      -> N
+ *   bytes  5    D      kernels.metal:606     / main.mm:827      -> D
+ *   bytes  6    scale  kernels.metal:607     / main.mm:828      -> scale
+ *   bytes  7,8  batch_stride, head_stride (elements)
+ *                      kernels.metal:608-609 / main.mm:835-839  -> batch_stride, head_stride
+ *   buffer 9    L_out  kernels.metal:611     / main.mm:840      -> lse  ([B,H,N] fp32)
+ *   bytes  10   is_causal kernels.metal:612  / main.mm:842-843  -> is_causal
+ *   grid (ceil(N/16), H, B) main.mm:846-852                     -> B, H (grid is the library's business)
+ *
+ * The other kernels the reference host dispatches by name
+ * (naive_attention_kernel kernels.metal:12, flash_attention_kernel :72,
+ * flash_attention_v2_kernel :462, flash_attention_simd_kernel :177;
+ * looked up at main.mm:69-95) are selected with `variant`.
+ *
+ * Conventions (mirroring main.mm): the caller owns every buffer, all pointers
+ * are DEVICE pointers, the library allocates nothing and keeps no state, the
+ * launch is asynchronous on `hip_stream` (hipStream_t, may be NULL = default
+ * stream) and re-entrant across devices/streams. Errors are returned, never
+ * exit()ed (main.mm:16-22 exits; a library must not).
+ */
+#ifndef FA_MI355_H
+#define FA_MI355_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_MI355_VERSION 100 /* major*10000 + minor*100 + patch */
+
+/* element type of Q, K, V and O */
+enum fa_dtype {
+  FA_DTYPE_F32 = 0,      /* naive / v1 / v2 variants (kernels.metal:12,72,462) */
+  FA_DTYPE_F16 = 1,      /* the reference operator's type (kernels.metal:601) */
+  FA_DTYPE_BF16 = 2,     /* BASELINE.json configs 3,4 */
+  FA_DTYPE_FP8_E4M3 = 3  /* Q,K,V OCP e4m3fn, O bf16 (BASELINE.json config 5) */
+};
+
+/* which kernel computes the operator */
+enum fa_variant {
+  FA_VARIANT_AUTO = 0,   /* fastest kernel that supports (dtype, D) */
+  FA_VARIANT_NAIVE = 1,  /* one thread per query row, two passes   (kernels.metal:12-64)   */
+  FA_VARIANT_TILED = 2,  /* LDS-tiled scalar "V1"                  (kernels.metal:72-171)  */
+  FA_VARIANT_TILED_V2 = 3, /* 128-bit loads, double-buffered K/V "V2" (kernels.metal:462-596) */
+  FA_VARIANT_MFMA = 4    /* matrix-core kernel "V3/V4"             (kernels.metal:177,600) */
+};
+
+/* status codes (0 = success, negative = error; text via fa_last_error()) */
+enum fa_status {
+  FA_OK = 0,
+  FA_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad enum, misaligned */
+  FA_ERR_UNSUPPORTED = -2,   /* (dtype, variant, D) combination has no kernel */
+  FA_ERR_LAUNCH = -3,        /* HIP runtime reported an error at launch */
+  FA_ERR_NO_DEVICE = -4      /* main.mm:42-45: no device */
+};
+
+/*
+ * The operator. O[b,h,i,:] = sum_j softmax_j(scale * Q[b,h,i,:].K[b,h,j,:]) V[b,h,j,:]
+ * with key j visible to query i iff (!is_causal || j <= i)   (kernels.metal:748);
+ * lse[b,h,i] = max_j(scale*s_ij) + ln(sum_j exp(scale*s_ij - max))  (kernels.metal:862-864),
+ * natural exp/log. Accumulation is fp32 for every dtype.
+ *
+ *  q,k,v,o       device pointers; element (b,h,i,d) at b*batch_stride + h*head_stride + i*D + d
+ *                (rows contiguous, row pitch D); 16-byte aligned, strides multiples of 8 elements
+ *  lse           device pointer to B*H*N floats, contiguous [B,H,N]; may be NULL
+ *  N             sequence length (queries == keys); any N >= 1
+ *  D             head dim: 64 or 128 for FA_VARIANT_MFMA, <= 128 (multiple of 4) otherwise
+ *  scale         softmax scale (> 0); the reference passes 1/sqrt(D) (main.mm:13)
+ *  dtype/variant enums above
+ *  hip_stream    hipStream_t on the current device, or NULL
+ */
+int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
+           int B, int H, int N, int D, float scale,
+           long long batch_stride, long long head_stride,
+           int is_causal, int dtype, int variant, void *hip_stream);
+
+/* 1 if fa_fwd has a kernel for the combination, else 0 (no GPU needed). */
+int fa_supported(int dtype, int variant, int D);
+
+/* variant FA_VARIANT_AUTO resolves to for (dtype, D); FA_ERR_UNSUPPORTED if none. */
+int fa_resolve_variant(int dtype, int D);
+
+/* bytes per element of Q/K/V and of O for a dtype (fp8: 1 and 2). 0 if bad enum. */
+int fa_dtype_in_bytes(int dtype);
+int fa_dtype_out_bytes(int dtype);
+
+/* algorithmic work of one fa_fwd call:
+ * flops = 4*B*H*N^2*D (2*.. causal); bytes = (3*in + out)*B*H*N*D + 4*B*H*N */
+double fa_algorithmic_flops(int B, int H, int N, int D, int is_causal);
+double fa_algorithmic_bytes(int B, int H, int N, int D, int dtype);
+
+/* thread-local text of the last error on this thread ("" if none). */
+const char *fa_last_error(void);
+
+int fa_version(void);
+const char *fa_variant_name(int variant);
+const char *fa_dtype_name(int dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FA_MI355_H */
