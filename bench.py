@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- attention-forward throughput on MI355X, one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+seqlen=4096, head_dim=64, batch=4, heads=16, bf16, is_causal=true PER GPU.
+The (batch, head) slices of the global [4*N_gpus, 16, 4096, 64] problem are
+block-distributed over ranks (flash_attention_metal_amd.shard.shard_heads):
+independent slices, no data-path collective, weak scaling. A "step" is one
+fa_fwd() launch over the rank's shard with Q/K/V already resident in HBM.
+
+Prints ONE JSON line on rank 0. `value` = algorithmic FLOPs of all ranks' steps
+/ max-over-ranks wall time of the K timed steps (barrier + synchronize on both
+sides). `roofline.achieved` is measured with HIP events on the launch stream
+around each of the same K launches. `cpu_baseline` times the reference's own
+CPU loop (oracle/_ref, kind "reference") or our C port of it (kind "port") on
+the host cores, rank 0 at N=1 only, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# configs[2] of BASELINE.json, per GPU
+B_PER_GPU, H, N, D = 4, 16, 4096, 64
+DTYPE = "bf16"
+CAUSAL = True
+PEAK_TFLOPS_BF16 = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16/f16
+PEAK_HBM_GBS = 8000.0      # 8 TB/s spec
+
+
+def cpu_baseline(target_s: float = 15.0) -> dict:
+    """Time the CPU path on a bounded sample of the workload: whole heads of
+    N=4096, D=64, causal, fp32 -- the reference's loop at /root/reference/main.mm:551-578."""
+    import numpy as np
+
+    import oracle  # test infrastructure: used here ONLY as the timed CPU baseline
+
+    q = oracle.init_random(N * D, 42).reshape(N, D)
+    k = oracle.init_random(N * D, 43).reshape(N, D)
+    v = oracle.init_random(N * D, 44).reshape(N, D)
+    flops_per_head = 2.0 * N * N * D  # causal convention, SURVEY.md 8(d)
+    if oracle.have_ref():
+        kind, cores = "reference", 1
+        fn = lambda: oracle.ref_causal(q, k, v)  # noqa: E731
+    else:
+        kind, cores = "port", 1
+        fn = lambda: oracle.causal(q, k, v, 0.125)  # noqa: E731
+    t0 = time.perf_counter()
+    fn()
+    t1 = time.perf_counter() - t0
+    heads = 1
+    total = t1
+    while total + t1 < target_s and heads < B_PER_GPU * H:
+        t0 = time.perf_counter()
+        fn()
+        total += time.perf_counter() - t0
+        heads += 1
+    return {
+        "value": round(flops_per_head * heads / total / 1e12, 6),
+        "unit": "TFLOP/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": f"{heads} of {B_PER_GPU * H} (batch,head) slices of the workload (N={N}, D={D}, causal, fp32), "
+                  f"{total:.1f} s single-threaded like the reference (main.mm:551-578)",
+        "seconds_per_head": round(total / heads, 3),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import flash_attention_metal_amd as fa
+    from flash_attention_metal_amd.shard import shard_heads
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the attention operator has no CPU path")
+    fa.load_library()  # fail loudly if the HIP library is missing
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # control plane only: barrier + max(time)
+
+    # ---- this rank's shard of the global (batch*head) slices -------------------------------
+    n_slices = B_PER_GPU * world * H
+    lo, hi = shard_heads(n_slices, world, rank)
+    my = hi - lo  # = B_PER_GPU * H
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    mk = lambda: (torch.rand(1, my, N, D, generator=g, device=dev, dtype=torch.float32) * 2 - 1).to(torch.bfloat16)  # noqa: E731
+    q, k, v = mk(), mk(), mk()  # random, never zeros (DVFS: zero data inflates MFMA clocks)
+    o = torch.empty_like(q)
+    lse = torch.empty(1, my, N, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        fa.flash_attention_forward(q, k, v, is_causal=CAUSAL, out=o, lse=lse)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    flops_step_rank = fa.algorithmic_flops(1, my, N, D, CAUSAL)
+    bytes_step_rank = fa.algorithmic_bytes(1, my, N, D, DTYPE)
+    total_flops = flops_step_rank * world * args.steps
+    value = total_flops / elapsed / 1e12
+
+    if rank == 0:
+        avg_ms = sum(kern_ms) / len(kern_ms)
+        achieved = flops_step_rank / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC pass result, if one was recorded
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "attn_fwd_tflops (seqlen=4096, head_dim=64, bf16, causal)",
+            "value": round(value, 3),
+            "unit": "TFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic uniform(-1,1) Q/K/V, resident in HBM",
+            "config": {"workload": "BASELINE.json configs[2]: seqlen=4096 head_dim=64 batch=4 heads=16 bf16 "
+                                   "is_causal=true per GPU",
+                       "batch_per_gpu": B_PER_GPU, "heads": H, "seq_len": N, "head_dim": D, "is_causal": CAUSAL,
+                       "sharding": f"(batch,head) slices block-distributed over {world} rank(s), no collective",
+                       "flops_per_step_per_gpu": flops_step_rank, "bytes_per_step_per_gpu": bytes_step_rank},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS_BF16,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_BF16, 4), "traffic": traffic,
+                         "kernel": "fa::fwd_mfma_kernel<BF16,64,causal>",
+                         "kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 5),
+                         "kernel_ms_min": round(kern_ms[0], 5),
+                         "hbm_frac": round(bytes_step_rank / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
+        }
+        if world == 1 and not args.no_sweep:
+            out["sweep"] = sweep(fa, torch, dev)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def sweep(fa, torch, dev):
+    """ms and TFLOP/s vs seqlen (the metric's other half): head_dim=64, bf16, causal, B*H=64."""
+    rows = []
+    for n in (128, 256, 512, 1024, 2048, 4096, 8192, 16384):
+        bh = 64
+        g = torch.Generator(device=dev).manual_seed(n)
+        mk = lambda: (torch.rand(1, bh, n, D, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)  # noqa: E731
+        q, k, v = mk(), mk(), mk()
+        o = torch.empty_like(q)
+        lse = torch.empty(1, bh, n, dtype=torch.float32, device=dev)
+        for _ in range(5):
+            fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+        iters = 30 if n <= 4096 else 10
+        evs = []
+        for _ in range(iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize(dev)
+        ms = sorted(a.elapsed_time(b) for a, b in evs)[iters // 2]
+        tf = fa.algorithmic_flops(1, bh, n, D, True) / (ms * 1e-3) / 1e12
+        rows.append({"seqlen": n, "ms": round(ms, 5), "tflops": round(tf, 2), "mfma_frac": round(tf / PEAK_TFLOPS_BF16, 4)})
+    return rows
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,8 @@ def _load() -> ctypes.CDLL:
                                     c_longlong, c_longlong, c_int, c_int]
     lib.oracle_attn_fwd_f64.argtypes = [_fp, _fp, _fp, _dp, _dp, c_int, c_int, c_int, c_int,
                                         c_float, c_longlong, c_longlong, c_int, c_int]
+    lib.oracle_attn_rows_f64.argtypes = [_fp, _fp, _fp, _dp, _dp, c_int, c_int, c_float, c_int,
+                                         POINTER(c_int), c_int, c_int]
     for name in ("oracle_round_f16", "oracle_round_bf16", "oracle_round_fp8_e4m3"):
         getattr(lib, name).argtypes = [_fp, c_longlong]
     lib.oracle_max_threads.restype = c_int
@@ -132,6 +134,21 @@ def attn_fwd_f64(q, k, v, is_causal: bool, scale: float | None = None, threads: 
     lse = np.empty((B, H, N), dtype=np.float64)
     lib().oracle_attn_fwd_f64(_f(q), _f(k), _f(v), _d(o), _d(lse), B, H, N, D, scale,
                               H * N * D, N * D, int(is_causal), threads)
+    return o, lse
+
+
+def attn_rows_f64(q, k, v, rows, is_causal: bool, scale: float | None = None, threads: int = 0):
+    """fp64 (O rows, LSE rows) for the query rows `rows` of one contiguous [N,D] head."""
+    N, D = q.shape
+    if scale is None:
+        scale = float(np.float32(1.0) / np.float32(np.sqrt(D)))
+    if threads <= 0:
+        threads = max_threads()
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    o = np.empty((len(rows), D), dtype=np.float64)
+    lse = np.empty(len(rows), dtype=np.float64)
+    lib().oracle_attn_rows_f64(_f(q), _f(k), _f(v), _d(o), _d(lse), N, D, scale, int(is_causal),
+                               rows.ctypes.data_as(POINTER(c_int)), len(rows), threads)
     return o, lse
 
 

@@ -252,6 +252,50 @@ void oracle_attn_fwd_f64(const float *q, const float *k, const float *v,
   }
 }
 
+/* selected query rows of ONE head in fp64: lets the full-size parity tests
+ * (N = 4096 .. 16384) check sampled rows without an O(N^2) pass per head */
+void oracle_attn_rows_f64(const float *q, const float *k, const float *v,
+                          double *o /*[nrows,D]*/, double *lse /*[nrows]*/,
+                          int N, int D, float scale, int is_causal,
+                          const int *rows, int nrows, int threads) {
+  if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+  {
+    double *scores = (double *)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (int t = 0; t < nrows; ++t) {
+      const int i = rows[t];
+      const float *qi = q + (long long)i * D;
+      int jmax = is_causal ? i : N - 1;
+      double m = -INFINITY;
+      for (int j = 0; j <= jmax; ++j) {
+        const float *kj = k + (long long)j * D;
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) s += (double)qi[d] * (double)kj[d];
+        s *= (double)scale;
+        scores[j] = s;
+        if (s > m) m = s;
+      }
+      double l = 0.0;
+      for (int j = 0; j <= jmax; ++j) {
+        scores[j] = exp(scores[j] - m);
+        l += scores[j];
+      }
+      for (int d = 0; d < D; ++d) {
+        double acc = 0.0;
+        for (int j = 0; j <= jmax; ++j) acc += scores[j] * (double)v[(long long)j * D + d];
+        o[(long long)t * D + d] = acc / l;
+      }
+      if (lse) lse[t] = m + log(l);
+    }
+    free(scores);
+  }
+}
+
 /* ------------------------------------------------------------------------- */
 /* RNE casts (main.mm:322-329 does fp32 -> __fp16 with a C cast)              */
 /* ------------------------------------------------------------------------- */

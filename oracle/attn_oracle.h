@@ -64,6 +64,12 @@ void oracle_attn_fwd_f64(const float *q, const float *k, const float *v,
                          int N, int D, float scale, long long batch_stride,
                          long long head_stride, int is_causal, int threads);
 
+/* fp64 result for selected query rows of one contiguous [N,D] head. */
+void oracle_attn_rows_f64(const float *q, const float *k, const float *v,
+                          double *o /*[nrows,D]*/, double *lse /*[nrows], nullable*/,
+                          int N, int D, float scale, int is_causal,
+                          const int *rows, int nrows, int threads);
+
 /* Round-to-nearest-even casts used to build 16-bit / fp8 test inputs
  * (main.mm:322-329 does the fp16 one with a __fp16 cast). In place, fp32 -> T
  * -> fp32. fp8 is OCP e4m3fn with saturation to +-448 (NaN stays NaN). */

@@ -1,0 +1,110 @@
+"""The C-ABI library: loads, exports every symbol include/fa_mi355.h declares,
+answers the no-GPU queries, and rejects bad arguments before any launch. CPU only."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import flash_attention_metal_amd as fa
+
+    if not os.path.exists(fa.lib_path()):
+        fa.build_library()
+    return fa
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "fa_mi355.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fa_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(fa):
+    names = declared_functions()
+    assert "fa_fwd" in names and "fa_last_error" in names and len(names) >= 10
+    lib = ctypes.CDLL(fa.lib_path())
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/fa_mi355.h but not exported"
+    from flash_attention_metal_amd._lib import SYMBOLS
+
+    assert sorted(SYMBOLS) == names  # the Python binding covers the whole header
+
+
+def test_version_and_names(fa):
+    lib = fa.load_library()
+    assert lib.fa_version() == 100
+    assert [lib.fa_variant_name(i).decode() for i in range(5)] == ["auto", "naive", "tiled", "tiled_v2", "mfma"]
+    assert [lib.fa_dtype_name(i).decode() for i in range(4)] == ["f32", "f16", "bf16", "fp8_e4m3"]
+
+
+def test_support_table(fa):
+    for d in (64, 128):
+        assert fa.supported("bf16", "mfma", d) and fa.supported("f16", "mfma", d)
+        assert not fa.supported("f32", "mfma", d)
+        for v in ("naive", "tiled", "tiled_v2"):
+            for t in ("f32", "f16", "bf16"):
+                assert fa.supported(t, v, d)
+    assert not fa.supported("bf16", "mfma", 48)
+    lib = fa.load_library()
+    assert lib.fa_resolve_variant(fa.DTYPES["bf16"], 64) == fa.VARIANTS["mfma"]
+    assert lib.fa_resolve_variant(fa.DTYPES["f32"], 64) == fa.VARIANTS["tiled_v2"]
+    assert lib.fa_resolve_variant(fa.DTYPES["f32"], 48) == -2
+
+
+def test_algorithmic_work_matches_survey_8d(fa):
+    # c3 = 1.3744e11 FLOP / 1.3527e8 B ; c2 = 2.1475e9 FLOP / 4.227e6 B
+    assert fa.algorithmic_flops(4, 16, 4096, 64, True) == 2.0 * 64 * 4096 * 4096 * 64
+    assert fa.algorithmic_bytes(4, 16, 4096, 64, "bf16") == 8 * 64 * 4096 * 64 + 4 * 64 * 4096
+    assert fa.algorithmic_flops(1, 8, 1024, 64, False) == 4.0 * 8 * 1024 * 1024 * 64
+    assert abs(fa.algorithmic_bytes(1, 8, 1024, 64, "f16") - 4.227e6) < 1e3
+    assert fa.algorithmic_bytes(4, 16, 8192, 64, "fp8_e4m3") == (3 + 2) * 64 * 8192 * 64 + 4 * 64 * 8192
+
+
+def test_bad_arguments_are_rejected_before_launch(fa):
+    lib = fa.load_library()
+    P = ctypes.c_void_p
+    ok = P(0x1000)
+
+    def call(q=ok, k=ok, v=ok, o=ok, B=1, H=1, N=128, D=64, scale=0.125, bs=None, hs=None, dtype=2, variant=0):
+        hs = N * D if hs is None else hs
+        bs = H * hs if bs is None else bs
+        return lib.fa_fwd(q, k, v, o, None, B, H, N, D, scale, bs, hs, 0, dtype, variant, None)
+
+    assert call(q=None) == -1 and b"null" in lib.fa_last_error()
+    assert call(N=0) == -1
+    assert call(scale=0.0) == -1 and b"scale" in lib.fa_last_error()
+    assert call(dtype=9) == -1
+    assert call(hs=100) == -1 and b"stride" in lib.fa_last_error()
+    assert call(q=P(0x1004)) == -1 and b"aligned" in lib.fa_last_error()
+    assert call(D=48) == -2 and b"no kernel" in lib.fa_last_error()
+    assert call(dtype=0, variant=4) == -2 and b"mfma" in lib.fa_last_error()
+    assert call(dtype=3) == -2  # fp8 has no kernel yet: reported, not faked
+
+
+def test_operator_refuses_cpu_tensors(fa):
+    import torch
+
+    x = torch.zeros(1, 1, 128, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fa.flash_attention_forward(x, x, x)
+
+
+def test_product_never_imports_the_oracle():
+    # the oracle is test infrastructure: nothing in the package or the driver may reference it
+    bad = []
+    for d in ("flash_attention_metal_amd", "driver", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, d)):
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".h", ".cpp", ".c", "Makefile")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"import oracle|from oracle|oracle/|libfa_oracle|attn_oracle", txt):
+                        # docstrings may MENTION that the oracle lives in oracle/: allow only that phrase
+                        for line in txt.splitlines():
+                            if re.search(r"import oracle|from oracle|libfa_oracle|attn_oracle\.h", line):
+                                bad.append((fn, line.strip()))
+    assert not bad, bad
