@@ -77,6 +77,21 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const lds_char *p) {
       (__attribute__((address_space(3))) s16x4 *)(p));
 }
 
+// Combine a per-lane value with the one held by lane^32 (the other half of the
+// same query row). v_permlane32_swap exchanges vdst[32..63] with src[0..31], so
+// with both operands holding x the pair becomes {x_lo|x_lo, x_hi|x_hi}
+// (checked on hardware: tools/probe_layouts.hip).
+// Inline asm on purpose: with __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2)
+// used the FIRST result for both elements here (.s: v_add_f32 v2, v34, v34), so
+// the halves never met. The s_nop covers the VALU-write -> permlane-read hazard
+// (2 wait states), which hipcc does not pad inside an asm string.
+__device__ __forceinline__ void half_pair(float x, float &lo, float &hi) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;
+  hi = b;
+}
+
 template <typename Tag, int D, bool CAUSAL>
 __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   using M = MT<Tag>;
@@ -245,9 +260,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 #pragma unroll
       for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s[0][i], s[1][i]));
       {
-        const unsigned u = __builtin_bit_cast(unsigned, mx);
-        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        float lo, hi;
+        half_pair(mx, lo, hi);
+        mx = fmaxf(lo, hi);
       }
       const float m_new = fmaxf(m, mx);
       if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {  // wave-uniform; exact skip when no max moved
@@ -294,9 +309,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 
   // ---- epilogue: normalise, LSE, O tile -> LDS -> coalesced 16-byte stores
   {
-    const unsigned u = __builtin_bit_cast(unsigned, l);
-    auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    l = __builtin_bit_cast(float, sw[0]) + __builtin_bit_cast(float, sw[1]);
+    float lo, hi;
+    half_pair(l, lo, hi);
+    l = lo + hi;
   }
   const float inv_l = 1.0f / l;
   if (p.lse != nullptr && h == 0 && qrow < p.N)
