@@ -85,6 +85,12 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const lds_char *p) {
 // used the FIRST result for both elements here (.s: v_add_f32 v2, v34, v34), so
 // the halves never met. The s_nop covers the VALU-write -> permlane-read hazard
 // (2 wait states), which hipcc does not pad inside an asm string.
+// one v_max3_f32; plain fmaxf on MFMA results costs an extra canonicalising v_max per operand
+__device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 __device__ __forceinline__ void half_pair(float x, float &lo, float &hi) {
   float a = x, b = x;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -215,6 +221,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 
   stage_load(0);
   stage_write(0);
+  // Retire the Q-fragment loads HERE: hipcc's waitcnt pass otherwise carries them into the
+  // loop as "possibly pending" and drains vmcnt(0) in front of every tile's first MFMAs, i.e.
+  // waits for the prefetch it has just issued (seen in the .s as vmcnt(3)..vmcnt(0)).
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
   __syncthreads();
 
   for (int t = 0; t < nT; ++t) {
@@ -256,9 +267,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
         }
       }
       // ---- online softmax, lane-local + one half swap
-      float mx = fmaxf(s[0][0], s[1][0]);
+      float mx = max3(s[0][0], s[1][0], s[0][1]);
+      mx = max3(mx, s[1][1], s[0][2]);
+      mx = max3(mx, s[1][2], s[0][3]);
 #pragma unroll
-      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, fmaxf(s[0][i], s[1][i]));
+      for (int i = 3; i < 15; i += 2) {
+        mx = max3(mx, s[1][i], s[0][i + 1]);
+        mx = max3(mx, s[1][i + 1], s[0][i + 2]);
+      }
+      mx = fmaxf(mx, s[1][15]);
       {
         float lo, hi;
         half_pair(mx, lo, hi);
