@@ -26,6 +26,8 @@
 //   * epilogue: O tile -> LDS -> whole 128-byte rows, 16 B per lane
 //   * grid: 1-D, heads dealt to XCDs (blocks b and b+8 share an L2) so one
 //     head's K/V stays in one L2; causal q-blocks heaviest first
+#include <type_traits>
+
 #include "fa_common.h"
 
 namespace fa {
@@ -85,12 +87,6 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const lds_char *p) {
 // used the FIRST result for both elements here (.s: v_add_f32 v2, v34, v34), so
 // the halves never met. The s_nop covers the VALU-write -> permlane-read hazard
 // (2 wait states), which hipcc does not pad inside an asm string.
-// one v_max3_f32; plain fmaxf on MFMA results costs an extra canonicalising v_max per operand
-__device__ __forceinline__ float max3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
 __device__ __forceinline__ void half_pair(float x, float &lo, float &hi) {
   float a = x, b = x;
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -109,6 +105,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   constexpr int DB = D / 32;                // 32-wide d blocks of O^T
   constexpr int TILE = BN * RB;             // bytes of one K (or V) tile
   constexpr int NCH = BN * CPR / NTHREADS;  // staged chunks per thread per tile
+  constexpr bool VPRE = (D == 64);          // prefetch V^T fragments under the QK^T MFMAs
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
@@ -228,8 +225,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
   __syncthreads();
 
-  for (int t = 0; t < nT; ++t) {
-    const int buf = t & 1;
+  // One KV tile; BUF (the LDS buffer holding tile t) is a compile-time constant so every
+  // LDS address is a per-lane base register plus an immediate.
+  auto tile = [&](auto bufc, const int t) {
+    constexpr int buf = decltype(bufc)::value;
     const int kv0 = t * BN;
     if (t + 1 < nT) stage_load(t + 1);  // in flight under this tile's MFMAs
 
@@ -240,6 +239,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
       const lds_char *Kt = Kbuf + buf * TILE;
       const lds_char *Vt = Vbuf + buf * TILE;
       // ---- S^T = K.Q^T : s[kb][reg] = S[q = r][key = kv0 + 32kb + (reg&3) + 8(reg>>2) + 4h]
+      // All K fragment reads are issued before the first MFMA, and (D = 64) the V^T
+      // fragments of the PV product are streamed in between the MFMAs, two transposed
+      // reads per MFMA: they do not depend on the softmax, so PV finds its operands in
+      // registers instead of waiting on LDS per MFMA. sched_barrier pins that order.
+      vec8 kf[2][KS];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          kf[kb][ks] = __builtin_bit_cast(vec8, lds_read_b128(Kt + kb * 32 * RB + koff[ks]));
+      __builtin_amdgcn_sched_barrier(0);
+      s16x4 vlo[VPRE ? 2 : 1][2][DB], vhi[VPRE ? 2 : 1][2][DB];
       f32x16 s[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -247,8 +258,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
         for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const vec8 a = __builtin_bit_cast(vec8, lds_read_b128(Kt + kb * 32 * RB + koff[ks]));
-          s[kb] = M::mfma(a, qf[ks], s[kb]);
+          s[kb] = M::mfma(kf[kb][ks], qf[ks], s[kb]);
+          if constexpr (VPRE) {
+            constexpr int PER = (2 * 2 * DB) / (2 * KS);  // V block reads per QK MFMA (1 at D=64)
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+              const int m = (kb * KS + ks) * PER + u;
+              const int vkb = m / (2 * DB), vst = (m / DB) % 2, vdb = m % DB;
+              const lds_char *vb = Vt + (32 * vkb + 16 * vst) * RB + voff[vdb];
+              vlo[vkb][vst][vdb] = lds_read_tr16(vb);
+              vhi[vkb][vst][vdb] = lds_read_tr16(vb + 8 * RB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       }
       // ---- mask (only on tiles that cross the diagonal or the end of the sequence)
@@ -267,15 +289,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
         }
       }
       // ---- online softmax, lane-local + one half swap
-      float mx = max3(s[0][0], s[1][0], s[0][1]);
-      mx = max3(mx, s[1][1], s[0][2]);
-      mx = max3(mx, s[1][2], s[0][3]);
+      float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-      for (int i = 3; i < 15; i += 2) {
-        mx = max3(mx, s[1][i], s[0][i + 1]);
-        mx = max3(mx, s[1][i + 1], s[0][i + 2]);
-      }
-      mx = fmaxf(mx, s[1][15]);
+      for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);  // -> v_max3_f32
       {
         float lo, hi;
         half_pair(mx, lo, hi);
@@ -311,9 +327,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
           for (int j = 0; j < 8; ++j) pf[j] = (elem)s[kb][8 * st + j];
 #pragma unroll
           for (int db = 0; db < DB; ++db) {
-            const lds_char *vb = Vt + (32 * kb + 16 * st) * RB + voff[db];
-            const s16x4 lo = lds_read_tr16(vb);           // keys +4h+0..3   (k elements 0..3)
-            const s16x4 hi = lds_read_tr16(vb + 8 * RB);  // keys +8+4h+0..3 (k elements 4..7)
+            s16x4 lo, hi;
+            if constexpr (VPRE) {
+              lo = vlo[kb][st][db];
+              hi = vhi[kb][st][db];
+            } else {
+              const lds_char *vb = Vt + (32 * kb + 16 * st) * RB + voff[db];
+              lo = lds_read_tr16(vb);           // keys +4h+0..3   (k elements 0..3)
+              hi = lds_read_tr16(vb + 8 * RB);  // keys +8+4h+0..3 (k elements 4..7)
+            }
             const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             oacc[db] = M::mfma(__builtin_bit_cast(vec8, v8), pf, oacc[db]);
           }
@@ -322,6 +344,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
     }
     if (t + 1 < nT) stage_write(buf ^ 1);
     __syncthreads();
+  };
+  for (int t = 0; t < nT; t += 2) {
+    tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nT) tile(std::integral_constant<int, 1>{}, t + 1);
   }
 
   // ---- epilogue: normalise, LSE, O tile -> LDS -> coalesced 16-byte stores

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of several builds of libfa_mi355.so in ONE process (cdna guide rule 24).
+usage: ab.py libA.so libB.so [...] [--shapes c3,nc8k,c16k] [--rounds 8] [--iters 20]"""
+import argparse, ctypes, os, sys
+from ctypes import c_int, c_float, c_longlong, c_void_p
+import torch
+
+SHAPES = {  # name: (B, H, N, D, dtype, causal)
+    "c3": (4, 16, 4096, 64, "bf16", 1), "nc4k": (4, 16, 4096, 64, "bf16", 0), "nc8k": (1, 64, 8192, 64, "bf16", 0),
+    "c16k": (1, 64, 16384, 64, "bf16", 1), "c2": (1, 8, 1024, 64, "f16", 0), "c4": (1, 32, 16384, 128, "bf16", 1),
+    "c1k": (4, 16, 1024, 64, "bf16", 1), "c2k": (4, 16, 2048, 64, "bf16", 1), "d128nc": (1, 32, 8192, 128, "bf16", 0),
+}
+ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--shapes", default="c3,nc8k,c16k")
+ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--variant", type=int, default=0)
+a = ap.parse_args()
+libs = []
+for p in a.libs:
+    l = ctypes.CDLL(os.path.abspath(p))
+    l.fa_fwd.restype = c_int
+    l.fa_fwd.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_float, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p]
+    libs.append(l)
+for name in a.shapes.split(","):
+    B, H, N, D, dt, causal = SHAPES[name]
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16}[dt]; fdt = {"f16": 1, "bf16": 2}[dt]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q, k, v = ((torch.rand(B, H, N, D, generator=g, device="cuda") * 2 - 1).to(tdt) for _ in range(3))
+    o = torch.empty_like(q); lse = torch.empty(B, H, N, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    def launch(l):
+        rc = l.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, D, D ** -0.5,
+                      H * N * D, N * D, causal, fdt, a.variant, st)
+        assert rc == 0, rc
+    outs = []
+    for l in libs:
+        for _ in range(3): launch(l)
+        torch.cuda.synchronize(); outs.append(o.clone())
+    res = [[] for _ in libs]
+    for r in range(a.rounds):
+        for i, l in enumerate(libs):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters): launch(l)
+            e1.record(); torch.cuda.synchronize()
+            res[i].append(e0.elapsed_time(e1) / a.iters)
+    fl = (2.0 if causal else 4.0) * B * H * N * N * D
+    line = f"{name:7s}"
+    for i, p in enumerate(a.libs):
+        ms = sorted(res[i]); med = ms[len(ms) // 2]
+        same = "" if i == 0 else (" same-bits" if torch.equal(outs[i], outs[0]) else f" maxdiff={(outs[i].float()-outs[0].float()).abs().max().item():.2e}")
+        line += f" | {os.path.basename(p)}: med {med*1e3:8.1f}us {fl/med/1e9:7.1f}TF best {fl/ms[0]/1e9:7.1f}TF{same}"
+    print(line, flush=True)
