@@ -1,0 +1,98 @@
+// fa_mfma_common.h -- types and lane-level helpers shared by the matrix-core kernels.
+#pragma once
+#include <type_traits>
+
+#include "fa_common.h"
+
+namespace fa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename Tag> struct MT;
+template <> struct MT<BF16> {
+  using elem = __bf16;
+  using vec8 = bf16x8;
+  __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MT<F16> {
+  using elem = _Float16;
+  using vec8 = f16x8;
+  __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int BM = 128;      // query rows per workgroup
+constexpr int WM = 32;       // query rows per wave
+constexpr int BN = 64;       // keys per tile
+constexpr int NTHREADS = 256;
+
+typedef __attribute__((address_space(3))) char lds_char;
+
+__device__ __forceinline__ u32x4 lds_read_b128(const lds_char *p) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(p);
+}
+__device__ __forceinline__ void lds_write_b128(lds_char *p, u32x4 v) {
+  *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(p) = v;
+}
+__device__ __forceinline__ void lds_write_b64(lds_char *p, u32x2 v) {
+  *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(p) = v;
+}
+// transposed 4x16 block read (ds_read_b64_tr_b16): lane i of a 16-lane group
+// receives column i of the 4 rows whose addresses lanes 4q+p supplied
+__device__ __forceinline__ s16x4 lds_read_tr16(const lds_char *p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(p));
+}
+
+// Combine a per-lane value with the one held by lane^32 (the other half of the
+// same query row). v_permlane32_swap exchanges vdst[32..63] with src[0..31], so
+// with both operands holding x the pair becomes {x_lo|x_lo, x_hi|x_hi}
+// (checked on hardware: tools/probe_layouts.hip).
+// Inline asm on purpose: with __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2)
+// used the FIRST result for both elements here (.s: v_add_f32 v2, v34, v34), so
+// the halves never met. The s_nop covers the VALU-write -> permlane-read hazard
+// (2 wait states), which hipcc does not pad inside an asm string.
+__device__ __forceinline__ void half_pair(float x, float &lo, float &hi) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = a;
+  hi = b;
+}
+
+// block id -> (batch*head, q block). Blocks b and b+8 share an XCD's L2 (observed dispatch
+// order; speed only, never correctness), so heads are dealt to the 8 residues: one head's
+// K/V then stays in one L2.
+//  * non-causal (uniform work): a head's q blocks are consecutive within its residue.
+//  * causal (q block i costs i+1 tiles): blocks are issued heaviest-first ACROSS all heads --
+//    q block nQ-1 of every head, then nQ-2 of every head, ... . Heavy-first only within a
+//    group of heads left the last group's 64-tile blocks starting late: measured 28 % over
+//    the ideal at N=4096 (simulated makespan 122 vs 88 tile-times; this order: 98).
+template <bool CAUSAL>
+__device__ __forceinline__ void map_block(int id, int BH, int nQ, int &bh, int &qb) {
+  if (CAUSAL) {
+    qb = nQ - 1 - id / BH;
+    bh = id % BH;  // BH % 8 == 0  =>  id % 8 == bh % 8: the head keeps its XCD residue
+    return;
+  }
+  const int full = (BH / 8) * 8;  // heads that can be dealt 8 at a time
+  if (id < full * nQ) {
+    const int xcd = id & 7, slot = id >> 3;
+    bh = (slot / nQ) * 8 + xcd;
+    qb = slot % nQ;
+  } else {
+    const int rem = id - full * nQ;
+    bh = full + rem / nQ;
+    qb = rem % nQ;
+  }
+}
+
+}  // namespace fa

@@ -26,73 +26,11 @@
 //   * epilogue: O tile -> LDS -> whole 128-byte rows, 16 B per lane
 //   * grid: 1-D, heads dealt to XCDs (blocks b and b+8 share an L2) so one
 //     head's K/V stays in one L2; causal q-blocks heaviest first
-#include <type_traits>
+#include <stdlib.h>
 
-#include "fa_common.h"
+#include "fa_mfma_common.h"
 
 namespace fa {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-template <typename Tag> struct MT;
-template <> struct MT<BF16> {
-  using elem = __bf16;
-  using vec8 = bf16x8;
-  __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct MT<F16> {
-  using elem = _Float16;
-  using vec8 = f16x8;
-  __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-
-constexpr int BM = 128;      // query rows per workgroup
-constexpr int WM = 32;       // query rows per wave
-constexpr int BN = 64;       // keys per tile
-constexpr int NTHREADS = 256;
-
-typedef __attribute__((address_space(3))) char lds_char;
-
-__device__ __forceinline__ u32x4 lds_read_b128(const lds_char *p) {
-  return *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(p);
-}
-__device__ __forceinline__ void lds_write_b128(lds_char *p, u32x4 v) {
-  *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(p) = v;
-}
-__device__ __forceinline__ void lds_write_b64(lds_char *p, u32x2 v) {
-  *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(p) = v;
-}
-// transposed 4x16 block read (ds_read_b64_tr_b16): lane i of a 16-lane group
-// receives column i of the 4 rows whose addresses lanes 4q+p supplied
-__device__ __forceinline__ s16x4 lds_read_tr16(const lds_char *p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4 *)(p));
-}
-
-// Combine a per-lane value with the one held by lane^32 (the other half of the
-// same query row). v_permlane32_swap exchanges vdst[32..63] with src[0..31], so
-// with both operands holding x the pair becomes {x_lo|x_lo, x_hi|x_hi}
-// (checked on hardware: tools/probe_layouts.hip).
-// Inline asm on purpose: with __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2)
-// used the FIRST result for both elements here (.s: v_add_f32 v2, v34, v34), so
-// the halves never met. The s_nop covers the VALU-write -> permlane-read hazard
-// (2 wait states), which hipcc does not pad inside an asm string.
-__device__ __forceinline__ void half_pair(float x, float &lo, float &hi) {
-  float a = x, b = x;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  lo = a;
-  hi = b;
-}
 
 template <typename Tag, int D, bool CAUSAL>
 __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
@@ -123,20 +61,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   const int nQ = (p.N + BM - 1) / BM;
   const int BH = p.B * p.H;
   int bh, qb;
-  {
-    const int id = blockIdx.x;
-    const int full = (BH / 8) * 8;  // heads that can be dealt 8 at a time
-    if (id < full * nQ) {
-      const int xcd = id & 7, slot = id >> 3;
-      bh = (slot / nQ) * 8 + xcd;
-      qb = slot % nQ;
-    } else {
-      const int rem = id - full * nQ;
-      bh = full + rem / nQ;
-      qb = rem % nQ;
-    }
-    if (CAUSAL) qb = nQ - 1 - qb;  // heaviest q blocks first
-  }
+  map_block<CAUSAL>(blockIdx.x, BH, nQ, bh, qb);
   const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
   const int q0 = qb * BM;
   const int qw0 = q0 + wave * WM;  // first query row of this wave
@@ -413,7 +338,10 @@ static hipError_t launch_dt(const Params &p, hipStream_t s) {
   return p.is_causal ? launch_one<Tag, 128, true>(p, s) : launch_one<Tag, 128, false>(p, s);
 }
 
+hipError_t launch_mfma_pipe_d64(const Params &p, int dtype, hipStream_t s);  // fa_mfma_pipe_kernel.hip
+
 hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s) {
+  if (p.D == 64 && getenv("FA_MFMA_PIPE")) return launch_mfma_pipe_d64(p, dtype, s);  // experimental software-pipelined kernel
   return dtype == FA_DTYPE_F16 ? launch_dt<F16>(p, s) : launch_dt<BF16>(p, s);
 }
 
