@@ -85,30 +85,25 @@ def main() -> None:
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
     import flash_attention_metal_amd as fa
-    from flash_attention_metal_amd.shard import shard_heads
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from flash_attention_metal_amd import ranks
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the attention operator has no CPU path")
+    fa.load_library()  # fail loudly if the HIP library is missing
+    info = ranks.init_ranks(use_gpu=True)  # backend "nccl" (= RCCL): control plane only (barrier + max/sum of scalars)
+    rank, local_rank, world = info.rank, info.local_rank, info.world
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the attention operator has no CPU path")
-    fa.load_library()  # fail loudly if the HIP library is missing
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # control plane only: barrier + max(time)
 
     # ---- this rank's shard of the global (batch*head) slices -------------------------------
-    n_slices = B_PER_GPU * world * H
-    lo, hi = shard_heads(n_slices, world, rank)
+    lo, hi = ranks.my_slices(info, B_PER_GPU * H)
     my = hi - lo  # = B_PER_GPU * H
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     mk = lambda: (torch.rand(1, my, N, D, generator=g, device=dev, dtype=torch.float32) * 2 - 1).to(torch.bfloat16)  # noqa: E731
@@ -121,10 +116,7 @@ def main() -> None:
         fa.flash_attention_forward(q, k, v, is_causal=CAUSAL, out=o, lse=lse)
 
     def barrier():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        ranks.barrier(info, dev)
 
     for _ in range(args.warmup):
         step()
@@ -138,15 +130,10 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = sorted(a.elapsed_time(b) for a, b in evs)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-
     flops_step_rank = fa.algorithmic_flops(1, my, N, D, CAUSAL)
     bytes_step_rank = fa.algorithmic_bytes(1, my, N, D, DTYPE)
-    total_flops = flops_step_rank * world * args.steps
-    value = total_flops / elapsed / 1e12
+    flops_per_s, elapsed = ranks.aggregate_throughput(info, flops_step_rank * args.steps, elapsed, dev)
+    value = flops_per_s / 1e12
 
     if rank == 0:
         avg_ms = sum(kern_ms) / len(kern_ms)
@@ -188,9 +175,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.finalize(info)
 
 
 def sweep(fa, torch, dev):

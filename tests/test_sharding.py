@@ -1,0 +1,79 @@
+"""(batch, head) sharding and the rank plumbing bench.py uses -- CPU only, incl. a world_size-2 gloo run."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_heads_is_a_partition():
+    from flash_attention_metal_amd.shard import shard_heads
+
+    for n in (0, 1, 7, 64, 256, 257):
+        for world in (1, 2, 3, 4, 8):
+            ranges = [shard_heads(n, world, r) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            for (a, b), (c, d) in zip(ranges, ranges[1:]):
+                assert b == c and a <= b and c <= d  # contiguous, disjoint, ordered
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1  # balanced
+    # BASELINE config 4: 8*32 = 256 slices over 8 GPUs -> 32 each
+    assert [shard_heads(256, 8, r) for r in (0, 7)] == [(0, 32), (224, 256)]
+    with pytest.raises(ValueError):
+        shard_heads(8, 2, 2)
+
+
+WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, os.environ["FA_ROOT"])
+import torch
+from flash_attention_metal_amd import ranks
+info = ranks.init_ranks(use_gpu=False)           # gloo
+lo, hi = ranks.my_slices(info, 64)               # bench.py: 64 (batch,head) slices per rank, weak scaling
+ranks.barrier(info)
+t0 = time.perf_counter()
+elapsed = 0.010 * (info.rank + 1)                # rank r "takes" 10(r+1) ms
+units = float(hi - lo) * 5                       # 5 steps over its slices
+value, worst = ranks.aggregate_throughput(info, units, elapsed)
+ranks.barrier(info)
+out = {"rank": info.rank, "world": info.world, "backend": info.backend, "lo": lo, "hi": hi, "value": value, "worst": worst}
+open(os.path.join(os.environ["FA_OUT"], f"rank{info.rank}.json"), "w").write(json.dumps(out))
+ranks.finalize(info)
+'''
+
+
+def test_two_ranks_gloo_aggregate():
+    with tempfile.TemporaryDirectory() as tmp:
+        script = os.path.join(tmp, "worker.py")
+        open(script, "w").write(WORKER)
+        env = dict(os.environ, FA_ROOT=ROOT, FA_OUT=tmp, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+        procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+        for p in procs:
+            assert p.wait(timeout=120) == 0
+        res = [json.load(open(os.path.join(tmp, f"rank{r}.json"))) for r in range(2)]
+    assert [r["backend"] for r in res] == ["gloo", "gloo"]
+    assert (res[0]["lo"], res[0]["hi"], res[1]["lo"], res[1]["hi"]) == (0, 64, 64, 128)  # disjoint, covering
+    for r in res:  # every rank sees: total units of all ranks / the slowest rank's time
+        assert r["worst"] == pytest.approx(0.020)
+        assert r["value"] == pytest.approx((64 * 5 + 64 * 5) / 0.020)
+
+
+def test_single_rank_needs_no_process_group():
+    from flash_attention_metal_amd import ranks
+
+    env_backup = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        info = ranks.init_ranks(use_gpu=False)
+        assert info.world == 1 and info.backend is None
+        assert ranks.my_slices(info, 64) == (0, 64)
+        assert ranks.aggregate_throughput(info, 10.0, 2.0) == (5.0, 2.0)
+        ranks.barrier(info)
+        ranks.finalize(info)
+    finally:
+        for k, v in env_backup.items():
+            if v is not None:
+                os.environ[k] = v
