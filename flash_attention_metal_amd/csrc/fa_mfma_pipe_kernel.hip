@@ -186,55 +186,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_pipe_d64_kernel(Params p
       const float mc = m * c2;
       const bool next_act = t + 1 < nTw;
       vec8 pf[2][2];
-      s16x4 vlo[2][2][DB], vhi[2][2][DB];
       float ls[2] = {0.0f, 0.0f};  // row-sum partials, accumulated right behind the exps
 
-      // softmax numerator of 4 score registers: sc <- exp2(c*sc - c*m); pack when 8 are done
-      auto soft4 = [&](int i) {  // i = 0..7: registers 4(i&3).. of block i>>2
+      // Softmax numerator in three stages over chunks of 4 score registers (chunk i = registers
+      // 4(i&3).. of key block i>>2). The stages of one chunk depend on each other, so a step issues
+      // stage F of chunk i+1, stage E of chunk i and stage S of chunk i-1: independent work only
+      // (with chunks run back to back the 4-wide fma -> exp -> add -> cvt chains stalled the wave).
+      auto stF = [&](int i) {  // x = c*s - c*m
         const int kb = i >> 2, b0 = 4 * (i & 3);
-        // zero-instruction anchor: pure VALU ops otherwise float above the MFMAs they should
-        // hide behind (sched_barrier does not bind LLVM's IR-level code motion)
         float mc_i = mc;
-        asm volatile("" : "+v"(mc_i));
+        asm volatile("" : "+v"(mc_i));  // zero-instruction anchor: keeps the fmas in this step
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sc[kb][b0 + j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][b0 + j], c2, -mc_i));
+        for (int j = 0; j < 4; ++j) sc[kb][b0 + j] = __builtin_fmaf(sc[kb][b0 + j], c2, -mc_i);
+      };
+      auto stE = [&](int i) {  // p = 2^x
+        const int kb = i >> 2, b0 = 4 * (i & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[kb][b0 + j] = __builtin_amdgcn_exp2f(sc[kb][b0 + j]);
+      };
+      auto stS = [&](int i) {  // row sum; pack to 16 bit when a PV fragment (8 registers) is complete
+        const int kb = i >> 2, b0 = 4 * (i & 3);
         ls[i & 1] += (sc[kb][b0] + sc[kb][b0 + 1]) + (sc[kb][b0 + 2] + sc[kb][b0 + 3]);
+        asm volatile("" : "+v"(ls[i & 1]));
         if (i & 1) {
           const int st = (i & 3) >> 1;
 #pragma unroll
           for (int j = 0; j < 8; ++j) pf[kb][st][j] = (elem)sc[kb][8 * st + j];
         }
       };
-      auto vread = [&](int mi) {  // V^T fragments of PV step mi = (kb, st, db)
-        const int vkb = mi / (2 * DB), vst = (mi / DB) % 2, vdb = mi % DB;
-        const lds_char *vb = Vt + (32 * vkb + 16 * vst) * RB + voff[vdb];
-        vlo[vkb][vst][vdb] = lds_read_tr16(vb);
-        vhi[vkb][vst][vdb] = lds_read_tr16(vb + 8 * RB);
-      };
-
-      // ---- phase B: O^T += V(t)^T.P(t)  ||  l += rowsum P(t), mx = rowmax S(t+1)
-      auto phase_b = [&](auto nextc) {
-        constexpr bool NEXT = decltype(nextc)::value;
-        float a0 = -INFINITY, a1 = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int kb = j >> 2, st = (j >> 1) & 1, db = j & 1;
-          const s16x8 v8 = __builtin_shufflevector(vlo[kb][st][db], vhi[kb][st][db], 0, 1, 2, 3, 4, 5, 6, 7);
-          oacc[db] = M::mfma(__builtin_bit_cast(vec8, v8), pf[kb][st], oacc[db]);
-          if (j < 4) vread(j + 4);  // V^T fragments of the second key block, one PV step group ahead
-          // 4 of the 32 row-max terms of the next tile ride behind each MFMA
-          if constexpr (NEXT) {
-            a0 = fmaxf(fmaxf(a0, sn[0][2 * j]), sn[0][2 * j + 1]);
-            a1 = fmaxf(fmaxf(a1, sn[1][2 * j]), sn[1][2 * j + 1]);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        l += ls[0] + ls[1];
-        if constexpr (NEXT) {
-          float lo, hi;
-          half_pair(fmaxf(a0, a1), lo, hi);
-          mx = fmaxf(lo, hi);
-        }
+      // Fragment reads are issued LA MFMAs ahead of their use and die at it (registers: the
+      // version that held all 24 fragments live needed 256 VGPRs and spilled).
+      constexpr int LA = 2;
+      vec8 kf[8];            // K fragment of QK step i = (kb = i>>2, ks = i&3)
+      s16x4 vlo[8], vhi[8];  // V^T fragment of PV step j = (kb = j>>2, st = (j>>1)&1, db = j&1)
+      auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(Kn + (i >> 2) * 32 * RB + koff[i & 3])); };
+      auto vread = [&](int j) {
+        const lds_char *vb = Vt + (32 * (j >> 2) + 16 * ((j >> 1) & 1)) * RB + voff[j & 1];
+        vlo[j] = lds_read_tr16(vb);
+        vhi[j] = lds_read_tr16(vb + 8 * RB);
       };
 
       // Phase A and phase B must stay ONE basic block (sched_barrier only binds the scheduler
@@ -244,43 +233,60 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_pipe_d64_kernel(Params p
         constexpr bool NEXT = decltype(nextc)::value, MASK = decltype(maskc)::value;
         if constexpr (NEXT) {
           // ---- phase A: S(t+1) = K(t+1).Q^T  ||  P(t)
-          // K fragments of key block 0 up front; those of block 1 are issued as block 0's are
-          // consumed, the V^T fragments of PV steps 0..3 ride along (the rest follow in phase B)
-          vec8 kf0[KS], kf1[KS];
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) kf0[ks] = __builtin_bit_cast(vec8, lds_read_b128(Kn + koff[ks]));
+          for (int i = 0; i < LA; ++i) kread(i);
           __builtin_amdgcn_sched_barrier(0);
+          f32x16 zero;
 #pragma unroll
-          for (int i = 0; i < 16; ++i) sn[0][i] = 0.0f;
+          for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+          stF(0);
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            sn[0] = M::mfma(kf0[ks], qf[ks], sn[0]);
-            kf1[ks] = __builtin_bit_cast(vec8, lds_read_b128(Kn + 32 * RB + koff[ks]));
-            vread(ks);
-            soft4(ks);
+          for (int i = 0; i < 8; ++i) {
+            sn[i >> 2] = M::mfma(kf[i], qf[i & 3], (i & 3) == 0 ? zero : sn[i >> 2]);  // C = 0 is an inline constant
+            if (i + LA < 8) kread(i + LA);
+            else vread(i + LA - 8);  // the last steps start the V^T stream of phase B
+            stE(i);
+            if (i + 1 < 8) stF(i + 1);
+            if (i >= 1) stS(i - 1);
             __builtin_amdgcn_sched_barrier(0);
           }
-#pragma unroll
-          for (int i = 0; i < 16; ++i) sn[1][i] = 0.0f;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            sn[1] = M::mfma(kf1[ks], qf[ks], sn[1]);
-            soft4(KS + ks);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+          stS(7);
           if constexpr (MASK) {
             apply_mask(sn, (t + 1) * BN);
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            if (i < 4) vread(i);
-            soft4(i);
+          for (int j = 0; j < LA; ++j) vread(j);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) stF(i);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) stE(i);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) stS(i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- phase B: O^T += V(t)^T.P(t)  ||  mx = rowmax S(t+1)
+        float a0 = -INFINITY, a1 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kb = j >> 2, st = (j >> 1) & 1, db = j & 1;
+          const s16x8 v8 = __builtin_shufflevector(vlo[j], vhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+          oacc[db] = M::mfma(__builtin_bit_cast(vec8, v8), pf[kb][st], oacc[db]);
+          if (j + LA < 8) vread(j + LA);
+          if constexpr (NEXT) {  // 4 of the 32 row-max terms of the next tile ride behind each MFMA
+            a0 = fmaxf(fmaxf(a0, sn[0][2 * j]), sn[0][2 * j + 1]);
+            a1 = fmaxf(fmaxf(a1, sn[1][2 * j]), sn[1][2 * j + 1]);
+            asm volatile("" : "+v"(a0), "+v"(a1));  // keep them behind this MFMA
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        phase_b(nextc);
+        l += ls[0] + ls[1];
+        if constexpr (NEXT) {
+          float lo, hi;
+          half_pair(fmaxf(a0, a1), lo, hi);
+          mx = fmaxf(lo, hi);
+        }
       };
       if (next_act) {
         if (needs_mask((t + 1) * BN))
