@@ -88,8 +88,9 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
   if (head_stride < (long long)N * D || batch_stride < 0 || (H > 1 && batch_stride < head_stride))
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: strides (batch %lld, head %lld) smaller than a head (N*D=%lld)",
                 batch_stride, head_stride, (long long)N * D);
-  if ((batch_stride % 8) || (head_stride % 8))
-    return fail(FA_ERR_INVALID_ARG, "fa_fwd: strides must be multiples of 8 elements");
+  const int stride_mult = dtype == FA_DTYPE_FP8_E4M3 ? 16 : 8;  // keeps every head 16-byte aligned
+  if ((batch_stride % stride_mult) || (head_stride % stride_mult))
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: strides must be multiples of %d elements", stride_mult);
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: tensors must be 16-byte aligned");
   if ((double)N * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)

@@ -30,12 +30,38 @@ template <> struct MT<F16> {
   }
 };
 
+template <> struct MT<FP8> {  // e4m3 inputs: converted to bf16 on the way into registers / LDS (exact),
+  using elem = __bf16;         // bf16 MFMA from there on (non-scaled fp8 MFMA has the same rate), O is bf16
+  using vec8 = bf16x8;
+  __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
 constexpr int BM = 128;      // query rows per workgroup
 constexpr int WM = 32;       // query rows per wave
 constexpr int BN = 64;       // keys per tile
 constexpr int NTHREADS = 256;
 
 typedef __attribute__((address_space(3))) char lds_char;
+
+// 8 OCP e4m3 values (two dwords) -> 8 bf16 (four dwords); exact: e4m3 is a subset of bf16
+__device__ __forceinline__ u32x4 fp8x8_to_bf16(u32x2 w) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  u32x4 out;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], false);
+    const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[i], true);
+    bf16x2 a, b;
+    a[0] = (__bf16)lo[0]; a[1] = (__bf16)lo[1];
+    b[0] = (__bf16)hi[0]; b[1] = (__bf16)hi[1];
+    out[2 * i] = __builtin_bit_cast(unsigned, a);
+    out[2 * i + 1] = __builtin_bit_cast(unsigned, b);
+  }
+  return out;
+}
 
 __device__ __forceinline__ u32x4 lds_read_b128(const lds_char *p) {
   return *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(p);

@@ -42,7 +42,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   constexpr int KS = D / 16;                // k-steps of the QK^T product
   constexpr int DB = D / 32;                // 32-wide d blocks of O^T
   constexpr int TILE = BN * RB;             // bytes of one K (or V) tile
-  constexpr int NCH = BN * CPR / NTHREADS;  // staged chunks per thread per tile
+  constexpr bool IS_FP8 = std::is_same<Tag, FP8>::value;  // Q,K,V are e4m3 in HBM, bf16 from LDS onwards
+  constexpr int GB = IS_FP8 ? 1 : 2;        // bytes per element in HBM
+  constexpr int GRB = D * GB;               // global row bytes
+  constexpr int GTILE = BN * GRB;           // global bytes of one K (or V) tile
+  constexpr int NCH = BN * (GRB / 16) / NTHREADS;  // staged 16-byte global chunks per thread per tile
   constexpr bool VPRE = (D == 64);          // prefetch V^T fragments under the QK^T MFMAs
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
@@ -67,21 +71,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   const int qw0 = q0 + wave * WM;  // first query row of this wave
   const int qrow = qw0 + r;
 
-  const unsigned head_bytes = (unsigned)p.N * RB;
+  const unsigned head_bytes = (unsigned)p.N * GRB;
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)((const elem *)p.q + base), 0, head_bytes, 0x00020000);
+      (void *)((const char *)p.q + base * GB), 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)((const elem *)p.k + base), 0, head_bytes, 0x00020000);
+      (void *)((const char *)p.k + base * GB), 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)((const elem *)p.v + base), 0, head_bytes, 0x00020000);
+      (void *)((const char *)p.v + base * GB), 0, head_bytes, 0x00020000);
 
   // ---- Q fragments (B operand of K.Q^T): lane (r,h) holds Q[qrow][16ks+8h .. +7].
   // Rows >= N read as zero through the descriptor's range check.
   vec8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + (2 * ks + h) * 16, 0, 0);
-    qf[ks] = __builtin_bit_cast(vec8, t);
+    if constexpr (IS_FP8) {
+      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rq, (unsigned)qrow * GRB + (2 * ks + h) * 8, 0, 0);
+      qf[ks] = __builtin_bit_cast(vec8, fp8x8_to_bf16(t));
+    } else {
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + (2 * ks + h) * 16, 0, 0);
+      qf[ks] = __builtin_bit_cast(vec8, t);
+    }
   }
 
   // ---- per-lane LDS offsets
@@ -100,16 +109,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
     voff[db] = (4 * h + vq) * RB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
 
   // ---- staging: thread -> NCH 16-byte chunks of the K tile and of the V tile
-  int st_g[NCH], st_k[NCH], st_v[NCH];
+  // (fp8: a 16-byte global chunk holds 16 elements = chunks 2c and 2c+1 of the bf16 row image in LDS,
+  //  each swizzled on its own: st_k/st_v address chunk 2c, st_k1/st_v1 chunk 2c+1)
+  constexpr int GCPR = GRB / 16;  // global chunks per row
+  int st_g[NCH], st_k[NCH], st_v[NCH], st_k1[IS_FP8 ? NCH : 1], st_v1[IS_FP8 ? NCH : 1];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = tid + i * NTHREADS;
-    const int row = c / CPR, ch = c % CPR;
-    st_g[i] = row * RB + ch * 16;
+    const int row = c / GCPR, gch = c % GCPR;
+    st_g[i] = row * GRB + gch * 16;
     const int skx = (D == 64) ? ((row >> 1) & 7) : (row & 15);
     const int svx = (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+    const int ch = IS_FP8 ? 2 * gch : gch;
     st_k[i] = row * RB + ((ch ^ skx) << 4);
     st_v[i] = row * RB + ((ch ^ svx) << 4);
+    if constexpr (IS_FP8) {
+      st_k1[i] = row * RB + (((ch + 1) ^ skx) << 4);
+      st_v1[i] = row * RB + (((ch + 1) ^ svx) << 4);
+    }
   }
 
   const int kv_end = CAUSAL ? min(p.N, q0 + BM) : p.N;
@@ -117,7 +134,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 
   u32x4 kst[NCH], vst[NCH];
   auto stage_load = [&](int t) {
-    const unsigned g0 = (unsigned)t * TILE;  // tile t starts at key t*BN
+    const unsigned g0 = (unsigned)t * GTILE;  // tile t starts at key t*BN
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, g0 + st_g[i], 0, 0);
@@ -127,8 +144,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   auto stage_write = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      lds_write_b128(Kbuf + buf * TILE + st_k[i], kst[i]);
-      lds_write_b128(Vbuf + buf * TILE + st_v[i], vst[i]);
+      if constexpr (IS_FP8) {  // e4m3 -> bf16 is exact; 16 elements = two bf16 chunks
+        lds_write_b128(Kbuf + buf * TILE + st_k[i], fp8x8_to_bf16(u32x2{kst[i][0], kst[i][1]}));
+        lds_write_b128(Kbuf + buf * TILE + st_k1[i], fp8x8_to_bf16(u32x2{kst[i][2], kst[i][3]}));
+        lds_write_b128(Vbuf + buf * TILE + st_v[i], fp8x8_to_bf16(u32x2{vst[i][0], vst[i][1]}));
+        lds_write_b128(Vbuf + buf * TILE + st_v1[i], fp8x8_to_bf16(u32x2{vst[i][2], vst[i][3]}));
+      } else {
+        lds_write_b128(Kbuf + buf * TILE + st_k[i], kst[i]);
+        lds_write_b128(Vbuf + buf * TILE + st_v[i], vst[i]);
+      }
     }
   };
 
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 
 // ---------------------------------------------------------------------------
 bool mfma_supported(int dtype, int D) {
-  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128);
+  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_FP8_E4M3) && (D == 64 || D == 128);
 }
 
 template <typename Tag, int D, bool CAUSAL>
@@ -341,7 +365,8 @@ static hipError_t launch_dt(const Params &p, hipStream_t s) {
 hipError_t launch_mfma_pipe_d64(const Params &p, int dtype, hipStream_t s);  // fa_mfma_pipe_kernel.hip
 
 hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s) {
-  if (p.D == 64 && getenv("FA_MFMA_PIPE")) return launch_mfma_pipe_d64(p, dtype, s);  // experimental software-pipelined kernel
+  if (p.D == 64 && dtype != FA_DTYPE_FP8_E4M3 && getenv("FA_MFMA_PIPE")) return launch_mfma_pipe_d64(p, dtype, s);  // experimental software-pipelined kernel
+  if (dtype == FA_DTYPE_FP8_E4M3) return launch_dt<FP8>(p, s);
   return dtype == FA_DTYPE_F16 ? launch_dt<F16>(p, s) : launch_dt<BF16>(p, s);
 }
 

@@ -44,7 +44,7 @@ enum fa_dtype {
   FA_DTYPE_F32 = 0,      /* naive / v1 / v2 variants (kernels.metal:12,72,462) */
   FA_DTYPE_F16 = 1,      /* the reference operator's type (kernels.metal:601) */
   FA_DTYPE_BF16 = 2,     /* BASELINE.json configs 3,4 */
-  FA_DTYPE_FP8_E4M3 = 3  /* Q,K,V OCP e4m3fn, O bf16 (BASELINE.json config 5) */
+  FA_DTYPE_FP8_E4M3 = 3  /* Q,K,V OCP e4m3fn, O bf16, fp32 accumulate (BASELINE.json config 5); MFMA variant only */
 };
 
 /* which kernel computes the operator */
@@ -72,7 +72,7 @@ enum fa_status {
  * natural exp/log. Accumulation is fp32 for every dtype.
  *
  *  q,k,v,o       device pointers; element (b,h,i,d) at b*batch_stride + h*head_stride + i*D + d
- *                (rows contiguous, row pitch D); 16-byte aligned, strides multiples of 8 elements
+ *                (rows contiguous, row pitch D); 16-byte aligned, strides multiples of 8 elements (16 for fp8)
  *  lse           device pointer to B*H*N floats, contiguous [B,H,N]; may be NULL
  *  N             sequence length (queries == keys); any N >= 1
  *  D             head dim: 64 or 128 for FA_VARIANT_MFMA, <= 128 (multiple of 4) otherwise

@@ -46,6 +46,7 @@ def test_support_table(fa):
     for d in (64, 128):
         assert fa.supported("bf16", "mfma", d) and fa.supported("f16", "mfma", d)
         assert not fa.supported("f32", "mfma", d)
+        assert fa.supported("fp8_e4m3", "mfma", d) and not fa.supported("fp8_e4m3", "tiled_v2", d)
         for v in ("naive", "tiled", "tiled_v2"):
             for t in ("f32", "f16", "bf16"):
                 assert fa.supported(t, v, d)
@@ -83,7 +84,8 @@ def test_bad_arguments_are_rejected_before_launch(fa):
     assert call(q=P(0x1004)) == -1 and b"aligned" in lib.fa_last_error()
     assert call(D=48) == -2 and b"no kernel" in lib.fa_last_error()
     assert call(dtype=0, variant=4) == -2 and b"mfma" in lib.fa_last_error()
-    assert call(dtype=3) == -2  # fp8 has no kernel yet: reported, not faked
+    assert call(dtype=3, variant=3) == -2  # fp8 inputs exist for the matrix-core variant only
+    assert call(dtype=3, hs=128 * 64 + 8) == -1  # fp8 heads must stay 16-byte aligned
 
 
 def test_operator_refuses_cpu_tensors(fa):

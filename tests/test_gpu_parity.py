@@ -94,6 +94,31 @@ def test_mfma_vs_oracle(fa, oracle_mod, dtype, D, causal):
         check(fa, oracle_mod, q, k, v, dtype, causal, "mfma")
 
 
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_mfma_fp8_inputs_vs_oracle(fa, oracle_mod, D, causal):
+    # BASELINE config 5 family: Q,K,V OCP e4m3fn (saturating RNE), fp32 accumulate, bf16 O.
+    # The oracle sees exactly the e4m3 values, so only P/O rounding (bf16) separates the two.
+    for (B, H, N) in ((1, 1, 128), (2, 3, 200), (1, 2, 65), (2, 2, 1000)):
+        for amp in (1.0, 3.0):  # amp 3: values up to 3 exercise more of the e4m3 grid
+            q, k, v = make_qkv(oracle_mod, B, H, N, D, "fp8", amp=amp)
+            o, lse = run_op(fa, q, k, v, "fp8", causal, "mfma")
+            o64, l64 = oracle_mod.attn_fwd_f64(q, k, v, causal)
+            assert np.abs(o - o64).max() < TOL_O["bf16"] * amp, (B, H, N, D, causal, amp)
+            assert np.abs(lse - l64).max() < 1e-4 * amp * amp
+
+
+def test_fp8_equals_bf16_kernel_on_same_values(fa, oracle_mod):
+    # e4m3 -> bf16 is exact, so the fp8-input kernel must reproduce the bf16 kernel bit for bit
+    import torch
+
+    q, k, v = make_qkv(oracle_mod, 2, 4, 320, 64, "fp8", amp=2.0)
+    for causal in (False, True):
+        o8, l8 = run_op(fa, q, k, v, "fp8", causal, "mfma")
+        ob, lb = run_op(fa, q, k, v, "bf16", causal, "mfma")
+        assert np.array_equal(o8, ob) and np.array_equal(l8, lb)
+
+
 def test_mfma_reference_mode_same_qkv_n1024(fa, oracle_mod):
     # main.mm:381-456 (V4 vs naive, N=1024, Q=K=V, fp16, tol 1e-2) and :458-594 (causal N=128)
     x = oracle_mod.round_to(oracle_mod.init_random(1024 * 64, 42).reshape(1, 1, 1024, 64), "f16")
@@ -250,6 +275,25 @@ def test_config2_full(fa, oracle_mod):  # seqlen=1024, D=64, B=1, H=8, fp16, non
 
 def test_config3_full(fa, oracle_mod):  # seqlen=4096, D=64, B=4, H=16, bf16, causal
     _full_size(fa, oracle_mod, 4, 16, 4096, 64, "bf16", True, [(0, 0), (1, 5), (3, 15)])
+
+
+def test_config5_full_fp8(fa, oracle_mod):  # seqlen=8192, D=64, fp8 in / fp32 acc, causal (B=4,H=16 assumed)
+    import torch
+
+    B, H, N, D = 4, 16, 8192, 64
+    g = torch.Generator(device="cuda").manual_seed(99)
+    q, k, v = (torch.rand(B, H, N, D, generator=g, device="cuda").mul_(2).sub_(1).to(torch.float8_e4m3fn) for _ in range(3))
+    o, lse = fa.flash_attention_forward(q, k, v, is_causal=True)
+    torch.cuda.synchronize()
+    assert o.dtype == torch.bfloat16 and torch.isfinite(o).all() and torch.isfinite(lse).all()
+    assert torch.equal(o[:, :, 0], v[:, :, 0].to(torch.bfloat16))  # causal row 0 == V[0]
+    rng = np.random.default_rng(3)
+    for (b, h) in ((0, 0), (3, 15)):
+        rows = np.unique(np.concatenate([[0, 1, 63, 64, 127, 128, N - 65, N - 64, N - 1], rng.integers(0, N, 32)])).astype(np.int32)
+        qh, kh, vh = (x[b, h].float().cpu().numpy() for x in (q, k, v))
+        o64, l64 = oracle_mod.attn_rows_f64(qh, kh, vh, rows, True)
+        assert np.abs(o[b, h].float().cpu().numpy()[rows] - o64).max() < TOL_O["bf16"]
+        assert np.abs(lse[b, h].cpu().numpy()[rows] - l64).max() < TOL_LSE["bf16"]
 
 
 def test_config4_per_gpu_slice_full(fa, oracle_mod):  # seqlen=16384, D=128, bf16 causal; one GPU's 32 (b,h) slices

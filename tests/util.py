@@ -1,7 +1,7 @@
 """Shared helpers for the parity tests (test side only: imports the oracle)."""
 import numpy as np
 
-TORCH_DTYPE = {"f32": "float32", "f16": "float16", "bf16": "bfloat16"}
+TORCH_DTYPE = {"f32": "float32", "f16": "float16", "bf16": "bfloat16", "fp8": "float8_e4m3fn"}
 
 
 def make_qkv(oracle, B, H, N, D, dtype, seeds=(42, 43, 44), amp=1.0):
