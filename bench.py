@@ -165,7 +165,7 @@ def main() -> None:
                        "flops_per_step_per_gpu": flops_step_rank, "bytes_per_step_per_gpu": bytes_step_rank},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS_BF16,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_BF16, 4), "traffic": traffic,
-                         "kernel": "fa::fwd_mfma_kernel<BF16,64,causal>",
+                         "kernel": "fa::fwd_mfma_kernel<fa::BF16, 64, true>",
                          "kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 5),
                          "kernel_ms_min": round(kern_ms[0], 5),
                          "hbm_frac": round(bytes_step_rank / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},

@@ -56,7 +56,8 @@ __global__ void fill_uniform(void *dst, size_t n, unsigned seed, int dtype) {
     const float u = (float)(z >> 40) * (2.0f / 16777216.0f) - 1.0f;
     if (dtype == FA_DTYPE_F32) ((float *)dst)[i] = u;
     else if (dtype == FA_DTYPE_F16) ((_Float16 *)dst)[i] = (_Float16)u;
-    else ((__bf16 *)dst)[i] = (__bf16)u;
+    else if (dtype == FA_DTYPE_BF16) ((__bf16 *)dst)[i] = (__bf16)u;
+    else ((unsigned char *)dst)[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(u, u, 0, false) & 0xff);  // OCP e4m3, RNE
   }
 }
 
@@ -342,7 +343,7 @@ static Timing run_config_sharded(const Config &c, int devices, int warmup, int i
     hipStream_t s;
     HIP_CHECK(hipStreamCreate(&s));
     const size_t ne = (size_t)mine * c.N * c.D;
-    DevBuf q(ne * elt(c.dtype)), k(ne * elt(c.dtype)), v(ne * elt(c.dtype)), o(ne * elt(c.dtype)), lse((size_t)mine * c.N * 4);
+    DevBuf q(ne * elt(c.dtype)), k(ne * elt(c.dtype)), v(ne * elt(c.dtype)), o(ne * (size_t)fa_dtype_out_bytes(c.dtype)), lse((size_t)mine * c.N * 4);
     fill_uniform<<<2048, 256, 0, s>>>(q.p, ne, 42 + 3 * lo, c.dtype);
     fill_uniform<<<2048, 256, 0, s>>>(k.p, ne, 43 + 3 * lo, c.dtype);
     fill_uniform<<<2048, 256, 0, s>>>(v.p, ne, 44 + 3 * lo, c.dtype);
@@ -373,6 +374,7 @@ static void run_configs(const Options &opt, std::ofstream &ext) {
       {"c2", 1, 8, 1024, 64, FA_DTYPE_F16, false},
       {"c3", 4, 16, 4096, 64, FA_DTYPE_BF16, true},
       {"c4", 8, 32, 16384, 128, FA_DTYPE_BF16, true},  // 8-GPU config: on G GPUs, G/8 of its (b,h) slices
+      {"c5", 4, 16, 8192, 64, FA_DTYPE_FP8_E4M3, true},  // fp8 in / fp32 accumulate / bf16 out (B,H assumed as c3)
   };
   for (const Config &c0 : cfgs) {
     for (int g = 1; g <= G; g *= 2) {

@@ -16,6 +16,7 @@ struct Params {
   float scale;
   long long batch_stride, head_stride;  // elements
   int is_causal;
+  int head_group = 0;  // internal: causal blocks are issued heaviest-first within groups of this many heads (0 = all)
 };
 
 // dtype tags

@@ -103,10 +103,14 @@ __device__ __forceinline__ void half_pair(float x, float &lo, float &hi) {
 //    group of heads left the last group's 64-tile blocks starting late: measured 28 % over
 //    the ideal at N=4096 (simulated makespan 122 vs 88 tile-times; this order: 98).
 template <bool CAUSAL>
-__device__ __forceinline__ void map_block(int id, int BH, int nQ, int &bh, int &qb) {
+__device__ __forceinline__ void map_block(int id, int BH, int nQ, int &bh, int &qb, int HG = 0) {
   if (CAUSAL) {
-    qb = nQ - 1 - id / BH;
-    bh = id % BH;  // BH % 8 == 0  =>  id % 8 == bh % 8: the head keeps its XCD residue
+    // heaviest-first within groups of HG heads (HG = BH: across all heads). A group keeps HG/8
+    // heads per XCD in flight, which bounds the K/V working set of that XCD's L2.
+    if (HG <= 0 || HG > BH || BH % HG != 0) HG = BH;
+    const int per = HG * nQ, g = id / per, rem = id - g * per;
+    qb = nQ - 1 - rem / HG;
+    bh = g * HG + rem % HG;  // HG % 8 == 0  =>  id % 8 == bh % 8: the head keeps its XCD residue
     return;
   }
   const int full = (BH / 8) * 8;  // heads that can be dealt 8 at a time
