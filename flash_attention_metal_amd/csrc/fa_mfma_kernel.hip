@@ -30,6 +30,10 @@
 
 #include "fa_mfma_common.h"
 
+#ifndef FA_PRIO
+#define FA_PRIO 2  // wave priority: 2 = raised around the MFMA clusters (+0.4..0.9 % A/B), 1 = around the softmax (-1..-6 %), 0 = off
+#endif
+
 namespace fa {
 
 template <typename Tag, int D, bool CAUSAL>
@@ -192,6 +196,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
       // fragments of the PV product are streamed in between the MFMAs, two transposed
       // reads per MFMA: they do not depend on the softmax, so PV finds its operands in
       // registers instead of waiting on LDS per MFMA. sched_barrier pins that order.
+#if FA_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
       vec8 kf[2][KS];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -237,6 +244,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
           }
         }
       }
+#if FA_PRIO == 1
+      __builtin_amdgcn_s_setprio(1);
+#elif FA_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
       // ---- online softmax, lane-local + one half swap
       float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
@@ -266,6 +278,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
         ls1 += s[1][i];
       }
       l += ls0 + ls1;
+#if FA_PRIO == 1
+      __builtin_amdgcn_s_setprio(0);
+#elif FA_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
       // ---- O^T += V^T.P^T : per 16-key step, P fragment = 8 accumulator registers
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {

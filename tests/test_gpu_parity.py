@@ -215,6 +215,27 @@ def test_head_batch_addressing_bit_exact(fa, oracle_mod, dtype):
     torch.cuda.synchronize()
 
 
+def test_torch_custom_op_matches_sdpa(fa, oracle_mod):
+    # the kernel as a torch operator, compared in-process with torch's own attention
+    import torch
+    import torch.nn.functional as F
+
+    from flash_attention_metal_amd import torch_op  # registers torch.ops.fa_mi355.attention_forward
+
+    q, k, v = (to_dev(x, "bf16") for x in make_qkv(oracle_mod, 2, 4, 384, 64, "bf16"))
+    for causal in (False, True):
+        o, lse = torch.ops.fa_mi355.attention_forward(q, k, v, causal, 0.0)
+        ref = F.scaled_dot_product_attention(q.float(), k.float(), v.float(), is_causal=causal)
+        assert (o.float() - ref).abs().max().item() < TOL_O["bf16"]
+        o2, lse2 = fa.flash_attention_forward(q, k, v, is_causal=causal)
+        assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    meta = torch.ops.fa_mi355.attention_forward(q.to("meta"), k.to("meta"), v.to("meta"), True, 0.0)
+    assert meta[0].shape == q.shape and meta[1].shape == (2, 4, 384) and meta[1].dtype == torch.float32
+    with pytest.raises(Exception):  # no CPU kernel is registered
+        torch.ops.fa_mi355.attention_forward(q.cpu(), k.cpu(), v.cpu(), False, 0.0)
+    torch.cuda.synchronize()
+
+
 def test_error_behaviour_on_device(fa):
     import torch
 
