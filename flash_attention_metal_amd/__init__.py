@@ -15,6 +15,7 @@ from .ops import (  # noqa: F401
     FaError,
     algorithmic_bytes,
     algorithmic_flops,
+    flash_attention_backward,
     flash_attention_forward,
     supported,
 )

@@ -14,6 +14,10 @@ _SO = os.path.join(_CSRC, "libfa_mi355.so")
 SYMBOLS = {
     "fa_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                        c_float, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p]),
+    "fa_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_longlong, c_longlong, c_int, c_int, c_void_p]),
+    "fa_bwd_workspace_bytes": (c_longlong, [c_int, c_int, c_int]),
+    "fa_bwd_supported": (c_int, [c_int, c_int]),
+    "fa_bwd_algorithmic_flops": (c_double, [c_int, c_int, c_int, c_int, c_int]),
     "fa_supported": (c_int, [c_int, c_int, c_int]),
     "fa_resolve_variant": (c_int, [c_int, c_int]),
     "fa_dtype_in_bytes": (c_int, [c_int]),

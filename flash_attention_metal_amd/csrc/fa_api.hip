@@ -129,4 +129,31 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
   return FA_OK;
 }
 
+long long fa_bwd_workspace_bytes(int B, int H, int N) { return (long long)B * H * N * 4; }
+int fa_bwd_supported(int dtype, int D) { return fa::bwd_supported(dtype, D); }
+double fa_bwd_algorithmic_flops(int B, int H, int N, int D, int is_causal) {
+  return 2.5 * fa_algorithmic_flops(B, H, N, D, is_causal);
+}
+
+int fa_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse, float *dq,
+           float *dk, float *dv, void *workspace, int B, int H, int N, int D, float scale, long long batch_stride,
+           long long head_stride, int is_causal, int dtype, void *hip_stream) {
+  g_err[0] = 0;
+  if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !workspace)
+    return fail(FA_ERR_INVALID_ARG, "fa_bwd: null pointer");
+  if (B < 1 || H < 1 || N < 1 || D < 1) return fail(FA_ERR_INVALID_ARG, "fa_bwd: B=%d H=%d N=%d D=%d must be >= 1", B, H, N, D);
+  if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "fa_bwd: scale=%g must be > 0", (double)scale);
+  if (head_stride < (long long)N * D || (H > 1 && batch_stride < head_stride) || (batch_stride % 8) || (head_stride % 8))
+    return fail(FA_ERR_INVALID_ARG, "fa_bwd: bad strides (batch %lld, head %lld)", batch_stride, head_stride);
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)
+    return fail(FA_ERR_INVALID_ARG, "fa_bwd: tensors must be 16-byte aligned");
+  if (!fa::bwd_supported(dtype, D))
+    return fail(FA_ERR_UNSUPPORTED, "fa_bwd: no kernel for dtype=%s D=%d (f16/bf16, D=64)", fa_dtype_name(dtype), D);
+  if ((double)N * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "fa_bwd: one head exceeds 4 GiB");
+  hipError_t e = fa::launch_bwd(q, k, v, o, d_o, lse, dq, dk, dv, (float *)workspace, B, H, N, D, scale, batch_stride,
+                                head_stride, is_causal ? 1 : 0, dtype, (hipStream_t)hip_stream);
+  if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_bwd: launch failed: %s", hipGetErrorString(e));
+  return FA_OK;
+}
+
 }  // extern "C"

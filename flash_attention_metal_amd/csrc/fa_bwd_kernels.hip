@@ -1,0 +1,447 @@
+// fa_bwd_kernels.hip -- backward of the operator on the CDNA4 matrix cores (head_dim 64).
+//
+// Replaces /root/reference/kernels.metal:905-1265 (flash_attention_backward_kernel): same
+// math -- D_i = rowsum(dO o O) (:983-990), P = exp(S*scale - L_i) recomputed from the forward's
+// LSE (:1082-1089), dV += P^T dO, dP = dO V^T, dS = P o (dP - D_i) * scale (:1160-1169),
+// dQ += dS K, dK += dS^T Q -- nothing else. The reference flushes dK/dV with global float
+// atomics from every Q block (:1221-1246); here no gradient is accumulated across workgroups:
+//
+//   bwd_delta_kernel   delta[b,h,i] = sum_d dO*O                       (workspace, B*H*N floats)
+//   bwd_dq_kernel      one workgroup per 128 query rows, loops over KV tiles (like the forward):
+//                        S^T = K.Q^T, dP^T = V.dO^T, dS^T = P^T o (dP^T - delta) * scale,
+//                        dQ^T += K^T.dS^T
+//   bwd_dkdv_kernel    one workgroup per 128 keys, loops over Q tiles:
+//                        S = Q.K^T, dP = dO.V^T, P, dS (as above),
+//                        dV^T += dO^T.P,  dK^T += Q^T.dS
+//
+// S and dP are computed twice (7 matrix products instead of 5) in exchange for deterministic,
+// atomic-free, bitwise reproducible gradients. Both kernels reuse the forward's machinery
+// (fa_mfma_kernel.hip): one operand's fragments live in registers, the other side streams
+// through double-buffered LDS tiles; the score tile comes out of v_mfma_f32_32x32x16 with the
+// reduction index of the NEXT product in its registers, so P / dS feed that product as the B
+// operand without leaving the register file, and the transposed A operands (K^T, dO^T, Q^T) are
+// ds_read_b64_tr_b16 reads of row-major tiles. A tile that is read both by rows and transposed
+// is kept in LDS twice, once per conflict-free swizzle.
+#include "fa_mfma_common.h"
+
+namespace fa {
+
+struct BwdParams {
+  const void *q, *k, *v, *o, *d_o;
+  const float *lse;
+  float *dq, *dk, *dv;
+  float *delta;  // workspace [B,H,N]
+  int B, H, N, D;
+  float scale;
+  long long batch_stride, head_stride;
+  int is_causal;
+};
+
+constexpr int BD = 64;        // head dim handled here
+constexpr int BRB = BD * 2;   // row bytes
+constexpr int BCPR = BD / 8;  // 16-byte chunks per row
+constexpr int BKS = BD / 16;
+constexpr int BDB = BD / 32;
+constexpr int BTILE = BN * BRB;  // one 64-row tile image
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int row_swz(int row) { return (row >> 1) & 7; }         // row-read image (ds_read_b128)
+__device__ __forceinline__ int tr_swz(int row) { return ((row >> 1) & 1) << 2; }   // transposed-read image
+
+// ---------------------------------------------------------------------------
+template <typename elem>
+__global__ __launch_bounds__(256) void bwd_delta_kernel(BwdParams p) {
+  // 8 lanes per row, 16 bytes each; 32 rows per block
+  const int tid = threadIdx.x;
+  const long long row = (long long)blockIdx.x * 32 + (tid >> 3);
+  const long long rows = (long long)p.B * p.H * p.N;
+  float acc = 0.0f;
+  if (row < rows) {
+    const long long bh = row / p.N, i = row % p.N;
+    const long long off = (bh / p.H) * p.batch_stride + (bh % p.H) * p.head_stride + i * BD + (tid & 7) * 8;
+    typedef elem e8 __attribute__((ext_vector_type(8)));
+    const e8 a = *reinterpret_cast<const e8 *>((const elem *)p.o + off);
+    const e8 b = *reinterpret_cast<const e8 *>((const elem *)p.d_o + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (row < rows && (tid & 7) == 0) p.delta[row] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
+// ---------------------------------------------------------------------------
+template <typename Tag, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, 2) void bwd_dq_kernel(BwdParams p) {
+  using M = MT<Tag>;
+  using vec8 = typename M::vec8;
+  using elem = typename M::elem;
+  extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+  lds_char *smem = (lds_char *)smem_generic;
+  lds_char *KR = smem;               // [2] K tile, row-read image
+  lds_char *KT = smem + 2 * BTILE;   // [2] K tile, transposed-read image
+  lds_char *VR = smem + 4 * BTILE;   // [2] V tile, row-read image
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int nQ = (p.N + BM - 1) / BM;
+  int bh, qb;
+  map_block<CAUSAL>(blockIdx.x, p.B * p.H, nQ, bh, qb);
+  const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
+  const int q0 = qb * BM, qw0 = q0 + wave * WM, qrow = qw0 + r;
+
+  const unsigned head_bytes = (unsigned)p.N * BRB;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.q + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.d_o + base), 0, head_bytes, 0x00020000);
+
+  vec8 qf[BKS], dof[BKS];  // B operands: lane (r,h) holds row qrow, columns 16ks+8h..
+#pragma unroll
+  for (int ks = 0; ks < BKS; ++ks) {
+    qf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * BRB + (2 * ks + h) * 16, 0, 0));
+    dof[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)qrow * BRB + (2 * ks + h) * 16, 0, 0));
+  }
+  // p*scale = exp2(c2*s - (lse*log2e - log2 scale)); rows past N get p = 0
+  const bool qvalid = qrow < p.N;
+  const float lse2 = qvalid ? p.lse[(long long)bh * p.N + qrow] * LOG2E - __log2f(p.scale) : INFINITY;
+  const float dlt = qvalid ? p.delta[(long long)bh * p.N + qrow] : 0.0f;
+  const float c2 = p.scale * LOG2E;
+
+  const int kx = row_swz(r);
+  int koff[BKS];
+#pragma unroll
+  for (int ks = 0; ks < BKS; ++ks) koff[ks] = r * BRB + (((2 * ks + h) ^ kx) << 4);
+  const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
+  const int vx = tr_swz(vq);
+  int voff[BDB];
+#pragma unroll
+  for (int db = 0; db < BDB; ++db) voff[db] = (4 * h + vq) * BRB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
+  constexpr int NCH = BN * BCPR / NTHREADS;  // 2
+  int st_g[NCH], st_r[NCH], st_t[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NTHREADS, row = c / BCPR, ch = c % BCPR;
+    st_g[i] = row * BRB + ch * 16;
+    st_r[i] = row * BRB + ((ch ^ row_swz(row)) << 4);
+    st_t[i] = row * BRB + ((ch ^ tr_swz(row)) << 4);
+  }
+  const int kv_end = CAUSAL ? min(p.N, q0 + BM) : p.N;
+  const int nT = (kv_end + BN - 1) / BN;
+
+  u32x4 kst[NCH], vst[NCH];
+  auto stage_load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)t * BTILE + st_g[i], 0, 0);
+      vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)t * BTILE + st_g[i], 0, 0);
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      lds_write_b128(KR + buf * BTILE + st_r[i], kst[i]);
+      lds_write_b128(KT + buf * BTILE + st_t[i], kst[i]);
+      lds_write_b128(VR + buf * BTILE + st_r[i], vst[i]);
+    }
+  };
+
+  f32x16 dqacc[BDB];
+#pragma unroll
+  for (int db = 0; db < BDB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dqacc[db][i] = 0.0f;
+
+  stage_load(0);
+  stage_write(0);
+#pragma unroll
+  for (int ks = 0; ks < BKS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));  // retire the prologue loads
+  __syncthreads();
+
+  for (int t = 0; t < nT; ++t) {
+    const int buf = t & 1, kv0 = t * BN;
+    if (t + 1 < nT) stage_load(t + 1);
+    if (!CAUSAL || kv0 <= qw0 + WM - 1) {
+      const lds_char *Kr = KR + buf * BTILE, *Kt = KT + buf * BTILE, *Vr = VR + buf * BTILE;
+      f32x16 s[2], dp[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[kb][i] = 0.0f; dp[kb][i] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < BKS; ++ks) {
+          const vec8 a = __builtin_bit_cast(vec8, lds_read_b128(Kr + kb * 32 * BRB + koff[ks]));
+          s[kb] = M::mfma(a, qf[ks], s[kb]);
+          const vec8 b = __builtin_bit_cast(vec8, lds_read_b128(Vr + kb * 32 * BRB + koff[ks]));
+          dp[kb] = M::mfma(b, dof[ks], dp[kb]);
+        }
+      }
+      if (CAUSAL && (kv0 + BN - 1 > qw0)) {  // key > query -> masked (kernels.metal:748)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int lim = qrow - kv0 - 32 * kb - 4 * h;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[kb][i] = ((i & 3) + 8 * (i >> 2) > lim) ? -INFINITY : s[kb][i];
+        }
+      }
+      // dS^T = (P^T * scale) o (dP^T - delta): keys in the registers, the query on the lane
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          s[kb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c2, -lse2)) * (dp[kb][i] - dlt);
+      // dQ^T += K^T.dS^T
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          vec8 df;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) df[j] = (elem)s[kb][8 * st + j];
+#pragma unroll
+          for (int db = 0; db < BDB; ++db) {
+            const lds_char *kb_ = Kt + (32 * kb + 16 * st) * BRB + voff[db];
+            const s16x8 k8 = __builtin_shufflevector(lds_read_tr16(kb_), lds_read_tr16(kb_ + 8 * BRB), 0, 1, 2, 3, 4, 5, 6, 7);
+            dqacc[db] = M::mfma(__builtin_bit_cast(vec8, k8), df, dqacc[db]);
+          }
+        }
+    }
+    if (t + 1 < nT) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+  // dQ^T[d][q]: lane (q = r, h) holds d = 32db + 8g4 + 4h + 0..3 -> one 16-byte store per group
+  if (qvalid) {
+    float *dq = p.dq + base + (long long)qrow * BD;
+#pragma unroll
+    for (int db = 0; db < BDB; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 w = make_float4(dqacc[db][4 * g4], dqacc[db][4 * g4 + 1], dqacc[db][4 * g4 + 2], dqacc[db][4 * g4 + 3]);
+        *reinterpret_cast<float4 *>(dq + 32 * db + 8 * g4 + 4 * h) = w;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dK, dV: workgroup = 128 keys, wave = 32 keys (key on the lane, queries in the registers)
+// ---------------------------------------------------------------------------
+template <typename Tag, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, 2) void bwd_dkdv_kernel(BwdParams p) {
+  using M = MT<Tag>;
+  using vec8 = typename M::vec8;
+  using elem = typename M::elem;
+  extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+  lds_char *smem = (lds_char *)smem_generic;
+  lds_char *QR = smem;                // [2] Q tile (64 rows), row-read image
+  lds_char *QT = smem + 2 * BTILE;    // [2] Q tile, transposed-read image
+  lds_char *OR_ = smem + 4 * BTILE;   // [2] dO tile, row-read image
+  lds_char *OT = smem + 6 * BTILE;    // [2] dO tile, transposed-read image
+  lds_char *ROWS = smem + 8 * BTILE;  // [2][2][64] floats: lse*log2e, delta of the tile's query rows
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int BH = p.B * p.H;
+  const int kvb = blockIdx.x / BH;  // ascending: under the causal mask the first key blocks see the most queries
+  const int bh = blockIdx.x % BH;
+  const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
+  const int k0 = kvb * BM, kw0 = k0 + wave * WM, krow = kw0 + r;
+
+  const unsigned head_bytes = (unsigned)p.N * BRB;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.q + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.d_o + base), 0, head_bytes, 0x00020000);
+
+  vec8 kf[BKS], vf[BKS];  // B operands: lane (r,h) holds key row krow, columns 16ks+8h..
+#pragma unroll
+  for (int ks = 0; ks < BKS; ++ks) {
+    kf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)krow * BRB + (2 * ks + h) * 16, 0, 0));
+    vf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)krow * BRB + (2 * ks + h) * 16, 0, 0));
+  }
+  const float c2 = p.scale * LOG2E;
+
+  const int kx = row_swz(r);
+  int koff[BKS];
+#pragma unroll
+  for (int ks = 0; ks < BKS; ++ks) koff[ks] = r * BRB + (((2 * ks + h) ^ kx) << 4);
+  const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
+  const int vx = tr_swz(vq);
+  int voff[BDB];
+#pragma unroll
+  for (int db = 0; db < BDB; ++db) voff[db] = (4 * h + vq) * BRB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
+  constexpr int NCH = BN * BCPR / NTHREADS;
+  int st_g[NCH], st_r[NCH], st_t[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NTHREADS, row = c / BCPR, ch = c % BCPR;
+    st_g[i] = row * BRB + ch * 16;
+    st_r[i] = row * BRB + ((ch ^ row_swz(row)) << 4);
+    st_t[i] = row * BRB + ((ch ^ tr_swz(row)) << 4);
+  }
+  // query tiles of 64 rows; under the causal mask only tiles that reach this block's first key
+  const int nTq = (p.N + BN - 1) / BN;
+  const int t_begin = CAUSAL ? k0 / BN : 0;
+
+  u32x4 qst[NCH], ost[NCH];
+  float rowv = 0.0f;  // threads 0..63: lse*log2e of row tid; 64..127: delta of row tid-64
+  auto stage_load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      qst[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)t * BTILE + st_g[i], 0, 0);
+      ost[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)t * BTILE + st_g[i], 0, 0);
+    }
+    if (tid < 128) {
+      const int qi = t * BN + (tid & 63);
+      if (tid < 64) rowv = qi < p.N ? p.lse[(long long)bh * p.N + qi] * LOG2E : INFINITY;  // p = 0 past N
+      else rowv = qi < p.N ? p.delta[(long long)bh * p.N + qi] : 0.0f;
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      lds_write_b128(QR + buf * BTILE + st_r[i], qst[i]);
+      lds_write_b128(QT + buf * BTILE + st_t[i], qst[i]);
+      lds_write_b128(OR_ + buf * BTILE + st_r[i], ost[i]);
+      lds_write_b128(OT + buf * BTILE + st_t[i], ost[i]);
+    }
+    if (tid < 128) lds_write_b32(ROWS + buf * 512 + tid * 4, __builtin_bit_cast(unsigned, rowv));
+  };
+
+  f32x16 dkacc[BDB], dvacc[BDB];
+#pragma unroll
+  for (int db = 0; db < BDB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dkacc[db][i] = 0.0f; dvacc[db][i] = 0.0f; }
+
+  if (t_begin < nTq) {
+    stage_load(t_begin);
+    stage_write(0);
+  }
+#pragma unroll
+  for (int ks = 0; ks < BKS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+  __syncthreads();
+
+  for (int t = t_begin; t < nTq; ++t) {
+    const int buf = (t - t_begin) & 1, qt0 = t * BN;
+    if (t + 1 < nTq) stage_load(t + 1);
+    if (!CAUSAL || qt0 + BN - 1 >= kw0) {  // some query of the tile sees this wave's first key
+      const lds_char *Qr = QR + buf * BTILE, *Qt = QT + buf * BTILE, *Or = OR_ + buf * BTILE, *Ot = OT + buf * BTILE;
+      const lds_char *rows = ROWS + buf * 512;
+      f32x16 s[2], dp[2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[qb][i] = 0.0f; dp[qb][i] = 0.0f; }
+#pragma unroll
+        for (int ks = 0; ks < BKS; ++ks) {
+          const vec8 a = __builtin_bit_cast(vec8, lds_read_b128(Qr + qb * 32 * BRB + koff[ks]));
+          s[qb] = M::mfma(a, kf[ks], s[qb]);
+          const vec8 b = __builtin_bit_cast(vec8, lds_read_b128(Or + qb * 32 * BRB + koff[ks]));
+          dp[qb] = M::mfma(b, vf[ks], dp[qb]);
+        }
+      }
+      // registers 4g..4g+3 of block qb are query rows 32qb + 8g + 4h + 0..3 of the tile
+      vec8 pf[2][2], df[2][2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ql = 32 * qb + 8 * g + 4 * h;
+          const u32x4 l4 = lds_read_b128(rows + ql * 4);
+          const u32x4 d4 = lds_read_b128(rows + 256 + ql * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int i = 4 * g + e;
+            // (scalar temporaries on purpose: __builtin_bit_cast applied directly to the vector
+            //  element expression l4[e] read element 0 for every e -- seen in the IR)
+            const unsigned lw = l4[e], dw = d4[e];
+            const float lse_q = __builtin_bit_cast(float, lw), delta_q = __builtin_bit_cast(float, dw);
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][i], c2, -lse_q));
+            if (CAUSAL && (qt0 + ql + e < krow)) pv = 0.0f;  // key > query (kernels.metal:748)
+            s[qb][i] = pv;
+            dp[qb][i] = pv * p.scale * (dp[qb][i] - delta_q);
+          }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            pf[qb][st][j] = (elem)s[qb][8 * st + j];
+            df[qb][st][j] = (elem)dp[qb][8 * st + j];
+          }
+      }
+      // dV^T += dO^T.P ; dK^T += Q^T.dS   (reduction over the tile's 64 query rows)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int db = 0; db < BDB; ++db) {
+            const int roff = (32 * qb + 16 * st) * BRB + voff[db];
+            const s16x8 o8 = __builtin_shufflevector(lds_read_tr16(Ot + roff), lds_read_tr16(Ot + roff + 8 * BRB), 0, 1, 2, 3, 4, 5, 6, 7);
+            dvacc[db] = M::mfma(__builtin_bit_cast(vec8, o8), pf[qb][st], dvacc[db]);
+            const s16x8 q8 = __builtin_shufflevector(lds_read_tr16(Qt + roff), lds_read_tr16(Qt + roff + 8 * BRB), 0, 1, 2, 3, 4, 5, 6, 7);
+            dkacc[db] = M::mfma(__builtin_bit_cast(vec8, q8), df[qb][st], dkacc[db]);
+          }
+    }
+    if (t + 1 < nTq) stage_write(buf ^ 1);
+    __syncthreads();
+  }
+  if (krow < p.N) {
+    float *dk = p.dk + base + (long long)krow * BD, *dv = p.dv + base + (long long)krow * BD;
+#pragma unroll
+    for (int db = 0; db < BDB; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 32 * db + 8 * g4 + 4 * h;
+        *reinterpret_cast<float4 *>(dk + d0) = make_float4(dkacc[db][4 * g4], dkacc[db][4 * g4 + 1], dkacc[db][4 * g4 + 2], dkacc[db][4 * g4 + 3]);
+        *reinterpret_cast<float4 *>(dv + d0) = make_float4(dvacc[db][4 * g4], dvacc[db][4 * g4 + 1], dvacc[db][4 * g4 + 2], dvacc[db][4 * g4 + 3]);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------
+bool bwd_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D == BD; }
+
+template <typename Tag>
+static hipError_t launch_bwd_dt(const BwdParams &p, hipStream_t s) {
+  using elem = typename MT<Tag>::elem;
+  const long long rows = (long long)p.B * p.H * p.N;
+  hipLaunchKernelGGL((bwd_delta_kernel<elem>), dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, p);
+  const int nB = (p.N + BM - 1) / BM;
+  const size_t smem_dq = 6 * BTILE, smem_kv = 8 * BTILE + 1024;
+  if (p.is_causal) {
+    auto kq = bwd_dq_kernel<Tag, true>;
+    auto kk = bwd_dkdv_kernel<Tag, true>;
+    hipError_t e = hipFuncSetAttribute((const void *)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kq, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
+    hipLaunchKernelGGL(kk, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_kv, s, p);
+  } else {
+    auto kq = bwd_dq_kernel<Tag, false>;
+    auto kk = bwd_dkdv_kernel<Tag, false>;
+    hipError_t e = hipFuncSetAttribute((const void *)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kq, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
+    hipLaunchKernelGGL(kk, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_kv, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
+                      float *dq, float *dk, float *dv, float *ws, int B, int H, int N, int D, float scale,
+                      long long bs, long long hs, int causal, int dtype, hipStream_t s) {
+  BwdParams p;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse = lse;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.delta = ws;
+  p.B = B; p.H = H; p.N = N; p.D = D; p.scale = scale;
+  p.batch_stride = bs; p.head_stride = hs; p.is_causal = causal;
+  return dtype == FA_DTYPE_F16 ? launch_bwd_dt<F16>(p, s) : launch_bwd_dt<BF16>(p, s);
+}
+
+}  // namespace fa

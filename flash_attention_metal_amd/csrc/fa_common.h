@@ -35,6 +35,10 @@ bool naive_supported(int dtype, int D);
 bool tiled_supported(int dtype, int D);
 bool tiled_v2_supported(int dtype, int D);
 bool mfma_supported(int dtype, int D);
+bool bwd_supported(int dtype, int D);
+hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
+                      float *dq, float *dk, float *dv, float *ws, int B, int H, int N, int D, float scale,
+                      long long bs, long long hs, int causal, int dtype, hipStream_t s);
 
 // ---- element load/store helpers for the scalar kernels -------------------
 __device__ __forceinline__ float ld_elem(const float *p, long long i) { return p[i]; }

@@ -9,8 +9,8 @@ namespace fa {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4), may_alias));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2), may_alias));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -68,6 +68,12 @@ __device__ __forceinline__ u32x4 lds_read_b128(const lds_char *p) {
 }
 __device__ __forceinline__ void lds_write_b128(lds_char *p, u32x4 v) {
   *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(p) = v;
+}
+// 4-byte LDS store that may alias the u32x4 loads above (a `float` store next to a `u32x4` load
+// of the same bytes is a strict-aliasing violation: hipcc then folded the 4 loaded lanes into one)
+typedef unsigned int __attribute__((may_alias)) u32_alias;
+__device__ __forceinline__ void lds_write_b32(lds_char *p, unsigned v) {
+  *reinterpret_cast<__attribute__((address_space(3))) u32_alias *>(p) = v;
 }
 __device__ __forceinline__ void lds_write_b64(lds_char *p, u32x2 v) {
   *reinterpret_cast<__attribute__((address_space(3))) u32x2 *>(p) = v;

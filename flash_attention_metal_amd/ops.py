@@ -100,3 +100,44 @@ def flash_attention_forward(
     if st != 0:
         raise FaError(st, lib.fa_last_error().decode())
     return out, lse
+
+
+def flash_attention_backward(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    o: torch.Tensor,
+    d_o: torch.Tensor,
+    lse: torch.Tensor,
+    is_causal: bool = False,
+    scale: Optional[float] = None,
+    stream: Optional[int] = None,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(Q,K,V,O,dO,LSE) -> (dQ,dK,dV) in fp32, same [B,H,N,D] layout (binding table of
+    /root/reference/kernels.metal:905-921; gradients are written, not accumulated)."""
+    lib = load_library()
+    if q.dim() != 4 or any(t.shape != q.shape for t in (k, v, o, d_o)):
+        raise ValueError("q, k, v, o, d_o must share one [B,H,N,D] shape")
+    if not all(t.is_cuda for t in (q, k, v, o, d_o, lse)):
+        raise RuntimeError("flash_attention_backward needs device tensors: there is no CPU path")
+    if q.dtype not in (torch.float16, torch.bfloat16) or any(t.dtype != q.dtype for t in (k, v, o, d_o)):
+        raise ValueError("backward supports f16 / bf16 tensors of one dtype")
+    B, H, N, D = q.shape
+    bs, hs = _strides(q)
+    if any(_strides(t) != (bs, hs) for t in (k, v, o, d_o)):
+        raise ValueError("all tensors must share batch/head strides")
+    if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != B * H * N:
+        raise ValueError("lse must be contiguous fp32 [B,H,N]")
+    dq, dk, dv = (torch.empty_strided((B, H, N, D), q.stride(), dtype=torch.float32, device=q.device) for _ in range(3))
+    ws = torch.empty(lib.fa_bwd_workspace_bytes(B, H, N), dtype=torch.uint8, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if stream is None:
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+    with torch.cuda.device(q.device):
+        st = lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+                        dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, H, N, D, float(scale), bs, hs,
+                        int(bool(is_causal)), _TORCH2FA[q.dtype], stream)
+    if st != 0:
+        raise FaError(st, lib.fa_last_error().decode())
+    return dq, dk, dv

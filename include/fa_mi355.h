@@ -85,6 +85,29 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
            long long batch_stride, long long head_stride,
            int is_causal, int dtype, int variant, void *hip_stream);
 
+/*
+ * Backward of the operator (row f1 of the scope table): the reference binds it as
+ * flash_attention_backward_kernel, /root/reference/kernels.metal:905-921, host side
+ * /root/reference/main.mm:1015-1058:
+ *   buffer 0-5  Q,K,V,O,dO (16-bit), L (fp32 [B,H,N], the forward's lse)   -> q,k,v,o,d_o,lse
+ *   buffer 6-8  dQ,dK,dV  fp32 (the reference accumulates into them with atomics and the host
+ *               zero-fills them first, main.mm:1018-1021)                  -> dq,dk,dv
+ *   bytes 9-14  N, D, scale, batch_stride, head_stride, is_causal          -> same names
+ * Here dq/dk/dv are WRITTEN (no zero-fill needed, no atomics, bitwise reproducible), laid out
+ * like the inputs (element (b,h,i,d) at b*batch_stride + h*head_stride + i*D + d, fp32).
+ * `workspace` is caller-owned scratch of fa_bwd_workspace_bytes(B,H,N) bytes (device memory).
+ * dtype F16 or BF16, D = 64.
+ */
+int fa_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
+           float *dq, float *dk, float *dv, void *workspace,
+           int B, int H, int N, int D, float scale,
+           long long batch_stride, long long head_stride,
+           int is_causal, int dtype, void *hip_stream);
+long long fa_bwd_workspace_bytes(int B, int H, int N);
+int fa_bwd_supported(int dtype, int D);
+/* algorithmic FLOPs of one fa_bwd call: 2.5x the forward (five N x N x D products) */
+double fa_bwd_algorithmic_flops(int B, int H, int N, int D, int is_causal);
+
 /* 1 if fa_fwd has a kernel for the combination, else 0 (no GPU needed). */
 int fa_supported(int dtype, int variant, int D);
 

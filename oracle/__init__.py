@@ -50,6 +50,7 @@ def _load() -> ctypes.CDLL:
                                         c_float, c_longlong, c_longlong, c_int, c_int]
     lib.oracle_attn_rows_f64.argtypes = [_fp, _fp, _fp, _dp, _dp, c_int, c_int, c_float, c_int,
                                          POINTER(c_int), c_int, c_int]
+    lib.oracle_attn_bwd_f64.argtypes = [_fp, _fp, _fp, _fp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, c_float, c_int, c_int]
     for name in ("oracle_round_f16", "oracle_round_bf16", "oracle_round_fp8_e4m3"):
         getattr(lib, name).argtypes = [_fp, c_longlong]
     lib.oracle_max_threads.restype = c_int
@@ -150,6 +151,18 @@ def attn_rows_f64(q, k, v, rows, is_causal: bool, scale: float | None = None, th
     lib().oracle_attn_rows_f64(_f(q), _f(k), _f(v), _d(o), _d(lse), N, D, scale, int(is_causal),
                                rows.ctypes.data_as(POINTER(c_int)), len(rows), threads)
     return o, lse
+
+
+def attn_bwd_f64(q, k, v, d_o, is_causal: bool, scale: float | None = None, threads: int = 0):
+    """fp64 (dQ, dK, dV) over contiguous [B,H,N,D] fp32 inputs."""
+    B, H, N, D = q.shape
+    if scale is None:
+        scale = float(np.float32(1.0) / np.float32(np.sqrt(D)))
+    if threads <= 0:
+        threads = max_threads()
+    dq, dk, dv = (np.empty(q.shape, dtype=np.float64) for _ in range(3))
+    lib().oracle_attn_bwd_f64(_f(q), _f(k), _f(v), _f(d_o), _d(dq), _d(dk), _d(dv), B, H, N, D, scale, int(is_causal), threads)
+    return dq, dk, dv
 
 
 def round_to(x: np.ndarray, dtype: str) -> np.ndarray:

@@ -297,6 +297,64 @@ void oracle_attn_rows_f64(const float *q, const float *k, const float *v,
 }
 
 /* ------------------------------------------------------------------------- */
+/* backward (fp64): dQ, dK, dV of the operator for upstream gradient dO.        */
+/* Math of /root/reference/kernels.metal:905-1265 (D_i at :983-990, P = exp(S*scale - L_i)  */
+/* at :1082-1089, dS = P*(dP - D_i)*scale at :1160-1169). The reference's own CPU check of   */
+/* it is broken (main.mm:1100-1101 value-casts bit patterns) and never looks at dK/dV:       */
+/* backward parity is UNPINNED by the reference; this fp64 statement is the anchor.          */
+/* ------------------------------------------------------------------------- */
+void oracle_attn_bwd_f64(const float *q, const float *k, const float *v, const float *d_o,
+                         double *dq, double *dk, double *dv, int B, int H, int N, int D,
+                         float scale, int is_causal, int threads) {
+  if (threads < 1) threads = 1;
+  const long long BH = (long long)B * H;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#endif
+  for (long long bh = 0; bh < BH; ++bh) {
+    const long long off = bh * (long long)N * D;
+    const float *Q = q + off, *K = k + off, *V = v + off, *DO = d_o + off;
+    double *DQ = dq + off, *DK = dk + off, *DV = dv + off;
+    for (long long i = 0; i < (long long)N * D; ++i) DQ[i] = DK[i] = DV[i] = 0.0;
+    double *p = (double *)malloc(sizeof(double) * (size_t)N);
+    double *o = (double *)malloc(sizeof(double) * (size_t)D);
+    for (int i = 0; i < N; ++i) {
+      const int jn = is_causal ? i + 1 : N;
+      double m = -INFINITY;
+      for (int j = 0; j < jn; ++j) {
+        double s = 0.0;
+        for (int d = 0; d < D; ++d) s += (double)Q[(long long)i * D + d] * (double)K[(long long)j * D + d];
+        s *= (double)scale;
+        p[j] = s;
+        if (s > m) m = s;
+      }
+      double l = 0.0;
+      for (int j = 0; j < jn; ++j) { p[j] = exp(p[j] - m); l += p[j]; }
+      for (int j = 0; j < jn; ++j) p[j] /= l;
+      for (int d = 0; d < D; ++d) {
+        double acc = 0.0;
+        for (int j = 0; j < jn; ++j) acc += p[j] * (double)V[(long long)j * D + d];
+        o[d] = acc;
+      }
+      double delta = 0.0;  /* D_i = rowsum(dO * O) */
+      for (int d = 0; d < D; ++d) delta += (double)DO[(long long)i * D + d] * o[d];
+      for (int j = 0; j < jn; ++j) {
+        double dp = 0.0;
+        for (int d = 0; d < D; ++d) dp += (double)DO[(long long)i * D + d] * (double)V[(long long)j * D + d];
+        const double ds = p[j] * (dp - delta) * (double)scale;
+        for (int d = 0; d < D; ++d) {
+          DV[(long long)j * D + d] += p[j] * (double)DO[(long long)i * D + d];
+          DQ[(long long)i * D + d] += ds * (double)K[(long long)j * D + d];
+          DK[(long long)j * D + d] += ds * (double)Q[(long long)i * D + d];
+        }
+      }
+    }
+    free(p);
+    free(o);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* RNE casts (main.mm:322-329 does fp32 -> __fp16 with a C cast)              */
 /* ------------------------------------------------------------------------- */
 static uint32_t f32_bits(float x) {

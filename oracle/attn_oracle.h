@@ -70,6 +70,12 @@ void oracle_attn_rows_f64(const float *q, const float *k, const float *v,
                           int N, int D, float scale, int is_causal,
                           const int *rows, int nrows, int threads);
 
+/* fp64 gradients of the operator over contiguous [B,H,N,D] (kernels.metal:905-1265 math).
+ * Backward parity is unpinned by the reference (its CPU check is broken, main.mm:1100-1101). */
+void oracle_attn_bwd_f64(const float *q, const float *k, const float *v, const float *d_o,
+                         double *dq, double *dk, double *dv, int B, int H, int N, int D,
+                         float scale, int is_causal, int threads);
+
 /* Round-to-nearest-even casts used to build 16-bit / fp8 test inputs
  * (main.mm:322-329 does the fp16 one with a __fp16 cast). In place, fp32 -> T
  * -> fp32. fp8 is OCP e4m3fn with saturation to +-448 (NaN stays NaN). */

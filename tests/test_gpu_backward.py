@@ -1,0 +1,114 @@
+"""GPU parity of the backward pass (scope row f1), through the C-ABI, against the fp64 CPU oracle.
+
+Reference: /root/reference/kernels.metal:905-1265. The reference's own CPU check of it is broken
+(main.mm:1100-1101 value-casts bit patterns; dK/dV are never compared), so backward parity is
+UNPINNED by the reference: the anchor is oracle_attn_bwd_f64 (cross-checked against torch autograd
+in fp64 by tests/test_oracle_backward.py). Tolerance: max|g - g_ref| / max|g_ref| per gradient tensor,
+  f16: 4e-3, bf16: 2e-2  (P and dS enter the second products rounded to 16 bits; the reference's bar is 1e-1, main.mm:1191).
+"""
+import numpy as np
+import pytest
+
+from util import make_qkv, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = {"f16": 4e-3, "bf16": 2e-2}
+
+
+@pytest.fixture(scope="module")
+def fa():
+    import torch
+
+    import flash_attention_metal_amd as fa
+
+    assert torch.cuda.is_available()
+    fa.load_library()
+    return fa
+
+
+def grads(fa, q, k, v, do, dtype, causal):
+    import torch
+
+    qd, kd, vd, dod = (to_dev(x, dtype) for x in (q, k, v, do))
+    o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal)
+    dq, dk, dv = fa.flash_attention_backward(qd, kd, vd, o, dod, lse, is_causal=causal)
+    torch.cuda.synchronize()
+    return dq.cpu().numpy(), dk.cpu().numpy(), dv.cpu().numpy()
+
+
+def rel(a, ref):
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_vs_oracle(fa, oracle_mod, dtype, causal):
+    for (B, H, N) in ((1, 1, 128), (2, 3, 200), (1, 2, 65), (1, 1, 1), (1, 1, 63), (1, 2, 129), (2, 2, 520)):
+        q, k, v = make_qkv(oracle_mod, B, H, N, 64, dtype)
+        do = oracle_mod.round_to(oracle_mod.init_random(B * H * N * 64, 45).reshape(B, H, N, 64), dtype)
+        dq, dk, dv = grads(fa, q, k, v, do, dtype, causal)
+        rq, rk, rv = oracle_mod.attn_bwd_f64(q, k, v, do, causal)
+        for name, g, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+            assert np.isfinite(g).all(), (name, B, H, N)
+            assert rel(g, ref) < TOL[dtype], (name, dtype, causal, B, H, N, rel(g, ref))
+
+
+def test_backward_known_answers(fa, oracle_mod):
+    import torch
+
+    # causal, row 0 attends to key 0 only: P = 1 -> dS = 0 -> dQ[0] = 0 exactly; dV[N-1] = P[N-1,N-1] * dO[N-1]
+    N = 192
+    q, k, v = make_qkv(oracle_mod, 1, 2, N, 64, "bf16")
+    do = oracle_mod.round_to(oracle_mod.init_random(2 * N * 64, 45).reshape(1, 2, N, 64), "bf16")
+    dq, dk, dv = grads(fa, q, k, v, do, "bf16", True)
+    assert np.count_nonzero(dq[:, :, 0]) == 0
+    # V = const: O = const, dP_ij = dO_i . v is the same for every j -> dS = 0 -> dQ = dK = 0 up to rounding
+    vc = np.full_like(v, 0.5)
+    dq, dk, dv = grads(fa, q, k, vc, do, "bf16", False)
+    assert np.abs(dq).max() < 2e-3 and np.abs(dk).max() < 2e-3
+    # column sums: sum_j dV[j,:] = sum_i dO[i,:] (softmax rows sum to 1)
+    np.testing.assert_allclose(dv.sum(2), do.sum(2), rtol=0, atol=2e-2 * np.abs(do.sum(2)).max() + 0.05)
+
+
+def test_backward_deterministic_and_matches_autograd(fa, oracle_mod):
+    import torch
+    import torch.nn.functional as F
+
+    q, k, v = make_qkv(oracle_mod, 2, 2, 384, 64, "bf16")
+    do = oracle_mod.round_to(oracle_mod.init_random(q.size, 45).reshape(q.shape), "bf16")
+    a = grads(fa, q, k, v, do, "bf16", True)
+    b = grads(fa, q, k, v, do, "bf16", True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)  # no atomics: bitwise reproducible
+    tq, tk, tv = (torch.tensor(x, dtype=torch.float64, requires_grad=True) for x in (q, k, v))
+    F.scaled_dot_product_attention(tq, tk, tv, is_causal=True).backward(torch.tensor(do, dtype=torch.float64))
+    for g, t in zip(a, (tq, tk, tv)):
+        assert rel(g, t.grad.numpy()) < TOL["bf16"]
+
+
+def test_backward_config3_shape_sampled_head(fa, oracle_mod):
+    # BASELINE config 3 shape family at reduced batch (B=1,H=4,N=4096): one head against the fp64 oracle
+    import torch
+
+    B, H, N = 1, 4, 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    q, k, v, do = (torch.rand(B, H, N, 64, generator=g, device="cuda").mul_(2).sub_(1).to(torch.bfloat16) for _ in range(4))
+    o, lse = fa.flash_attention_forward(q, k, v, is_causal=True)
+    dq, dk, dv = fa.flash_attention_backward(q, k, v, o, do, lse, is_causal=True)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(t).all() for t in (dq, dk, dv))
+    h = 3
+    f = lambda t: np.ascontiguousarray(t[:, h:h + 1].float().cpu().numpy())  # noqa: E731
+    rq, rk, rv = oracle_mod.attn_bwd_f64(f(q), f(k), f(v), f(do), True)
+    for gq, ref in ((dq, rq), (dk, rk), (dv, rv)):
+        assert rel(gq[:, h:h + 1].cpu().numpy(), ref) < TOL["bf16"]
+
+
+def test_backward_errors(fa):
+    import torch
+
+    x = torch.zeros(1, 1, 128, 128, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(1, 1, 128, device="cuda")
+    with pytest.raises(fa.FaError) as e:
+        fa.flash_attention_backward(x, x, x, x, x, lse)
+    assert e.value.status == -2  # head_dim 128 backward not built: reported, not faked
