@@ -298,7 +298,7 @@ static void run_sweep(const Options &opt, std::ofstream &ext) {
   }
 }
 
-// ---- phase 4: B=16, H=8 run (main.mm:881-1013; its backward column is out of scope: 0) --------
+// ---- phase 4: B=16, H=8 run, forward and backward (main.mm:881-1066) ---------------------------
 static void run_high_occupancy(const Options &opt, std::ofstream &ext) {
   const int B = 16, H = 8, D = 64;
   std::cout << "\n--- High Occupancy Benchmark (B=16, H=8) ---\n";
@@ -314,7 +314,37 @@ static void run_high_occupancy(const Options &opt, std::ofstream &ext) {
     const int it = n >= 4096 ? std::max(3, opt.iters / 4) : opt.iters;
     Timing t2 = time_forward(FA_VARIANT_TILED_V2, FA_DTYPE_F16, hq, hk, hv, ho, nullptr, B, H, n, D, false, 1, std::min(it, 3));
     Timing t4 = time_forward(FA_VARIANT_MFMA, FA_DTYPE_F16, hq, hk, hv, ho, (float *)lse.p, B, H, n, D, false, opt.warmup, it);
-    std::cout << n << "," << t2.median_ms << "," << t4.median_ms << "," << 0 << "," << t2.median_ms / t4.median_ms << std::endl;
+    // backward (main.mm:1015-1066): dO random, gradients fp32; O and LSE come from the forward above
+    double bwd_ms = 0.0;
+    {
+      DevBuf d_o(ne * 2), dq(ne * 4), dk(ne * 4), dv(ne * 4), ws((size_t)fa_bwd_workspace_bytes(B, H, n));
+      fill_uniform<<<1024, 256>>>(d_o.p, ne, 45, FA_DTYPE_F16);
+      HIP_CHECK(hipDeviceSynchronize());
+      auto bwd = [&]() {
+        fa_check(fa_bwd(hq.p, hk.p, hv.p, ho.p, d_o.p, (const float *)lse.p, (float *)dq.p, (float *)dk.p, (float *)dv.p, ws.p, B, H,
+                        n, D, 1.0f / std::sqrt((float)D), (long long)H * n * D, (long long)n * D, 0, FA_DTYPE_F16, nullptr));
+      };
+      for (int i = 0; i < 2; ++i) bwd();
+      const int bit = std::max(3, it / 2);
+      std::vector<hipEvent_t> ev(2 * bit);
+      for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
+      for (int i = 0; i < bit; ++i) {
+        HIP_CHECK(hipEventRecord(ev[2 * i], nullptr));
+        bwd();
+        HIP_CHECK(hipEventRecord(ev[2 * i + 1], nullptr));
+      }
+      HIP_CHECK(hipDeviceSynchronize());
+      std::vector<float> ms(bit);
+      for (int i = 0; i < bit; ++i) HIP_CHECK(hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]));
+      for (auto &e : ev) (void)hipEventDestroy(e);
+      std::sort(ms.begin(), ms.end());
+      bwd_ms = ms[bit / 2];
+      if (ext.is_open()) {
+        const double tf = fa_bwd_algorithmic_flops(B, H, n, D, 0) / (bwd_ms * 1e-3) / 1e12;
+        ext << n << ",mfma_bwd,f16,0," << B << "," << H << "," << D << ",1," << bwd_ms << "," << ms[0] << "," << tf << "," << tf / PEAK_TFLOPS << ",\n";
+      }
+    }
+    std::cout << n << "," << t2.median_ms << "," << t4.median_ms << "," << bwd_ms << "," << t2.median_ms / t4.median_ms << std::endl;
     ext_row(ext, n, "tiled_v2", FA_DTYPE_F16, false, B, H, D, t2);
     ext_row(ext, n, "mfma", FA_DTYPE_F16, false, B, H, D, t4);
   }
