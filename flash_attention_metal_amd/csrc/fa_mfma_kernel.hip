@@ -199,23 +199,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 #if FA_PRIO == 2
       __builtin_amdgcn_s_setprio(1);
 #endif
-      vec8 kf[2][KS];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          kf[kb][ks] = __builtin_bit_cast(vec8, lds_read_b128(Kt + kb * 32 * RB + koff[ks]));
-      __builtin_amdgcn_sched_barrier(0);
-      s16x4 vlo[VPRE ? 2 : 1][2][DB], vhi[VPRE ? 2 : 1][2][DB];
       f32x16 s[2];
+      s16x4 vlo[VPRE ? 2 : 1][2][DB], vhi[VPRE ? 2 : 1][2][DB];
+      if constexpr (VPRE) {
+        vec8 kf[2][KS];
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
+          for (int ks = 0; ks < KS; ++ks)
+            kf[kb][ks] = __builtin_bit_cast(vec8, lds_read_b128(Kt + kb * 32 * RB + koff[ks]));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          s[kb] = M::mfma(kf[kb][ks], qf[ks], s[kb]);
-          if constexpr (VPRE) {
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s[kb] = M::mfma(kf[kb][ks], qf[ks], s[kb]);
             constexpr int PER = (2 * 2 * DB) / (2 * KS);  // V block reads per QK MFMA (1 at D=64)
 #pragma unroll
             for (int u = 0; u < PER; ++u) {
@@ -227,6 +227,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
             }
             __builtin_amdgcn_sched_barrier(0);
           }
+        }
+      } else {
+        // head_dim 128: 16 K fragments would cost 64 VGPRs if held live; read each one LA MFMAs ahead of
+        // its use instead (profile before: 9 % of wave time stalled on LDS issue, 14 % MFMA/VALU co-execution)
+        constexpr int NK = 2 * KS, LA = 2;
+        vec8 kf[NK];
+        auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(Kt + (i / KS) * 32 * RB + koff[i % KS])); };
+#pragma unroll
+        for (int i = 0; i < LA; ++i) kread(i);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 zero;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+          s[i / KS] = M::mfma(kf[i], qf[i % KS], (i % KS) == 0 ? zero : s[i / KS]);
+          if (i + LA < NK) kread(i + LA);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       // ---- mask (only on tiles that cross the diagonal or the end of the sequence)
@@ -284,27 +302,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
       __builtin_amdgcn_s_setprio(1);
 #endif
       // ---- O^T += V^T.P^T : per 16-key step, P fragment = 8 accumulator registers
+      if constexpr (VPRE) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          vec8 pf;
+          for (int st = 0; st < 2; ++st) {
+            vec8 pf;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pf[j] = (elem)s[kb][8 * st + j];
+            for (int j = 0; j < 8; ++j) pf[j] = (elem)s[kb][8 * st + j];
 #pragma unroll
-          for (int db = 0; db < DB; ++db) {
-            s16x4 lo, hi;
-            if constexpr (VPRE) {
-              lo = vlo[kb][st][db];
-              hi = vhi[kb][st][db];
-            } else {
-              const lds_char *vb = Vt + (32 * kb + 16 * st) * RB + voff[db];
-              lo = lds_read_tr16(vb);           // keys +4h+0..3   (k elements 0..3)
-              hi = lds_read_tr16(vb + 8 * RB);  // keys +8+4h+0..3 (k elements 4..7)
+            for (int db = 0; db < DB; ++db) {
+              const s16x8 v8 = __builtin_shufflevector(vlo[kb][st][db], vhi[kb][st][db], 0, 1, 2, 3, 4, 5, 6, 7);
+              oacc[db] = M::mfma(__builtin_bit_cast(vec8, v8), pf, oacc[db]);
             }
-            const s16x8 v8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            oacc[db] = M::mfma(__builtin_bit_cast(vec8, v8), pf, oacc[db]);
           }
+        }
+      } else {
+        // V^T fragments just in time, LA MFMAs ahead (step j = (kb, st, db))
+        constexpr int NV = 2 * 2 * DB, LA = 2;
+        s16x4 wlo[NV], whi[NV];
+        auto vread = [&](int j) {
+          const lds_char *vb = Vt + (32 * (j / (2 * DB)) + 16 * ((j / DB) % 2)) * RB + voff[j % DB];
+          wlo[j] = lds_read_tr16(vb);           // keys +4h+0..3   (k elements 0..3)
+          whi[j] = lds_read_tr16(vb + 8 * RB);  // keys +8+4h+0..3 (k elements 4..7)
+        };
+        vec8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[kb][st][j] = (elem)s[kb][8 * st + j];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) vread(j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const s16x8 v8 = __builtin_shufflevector(wlo[j], whi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+          oacc[j % DB] = M::mfma(__builtin_bit_cast(vec8, v8), pf[j / (2 * DB)][(j / DB) % 2], oacc[j % DB]);
+          if (j + LA < NV) vread(j + LA);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }

@@ -215,6 +215,24 @@ def test_head_batch_addressing_bit_exact(fa, oracle_mod, dtype):
     torch.cuda.synchronize()
 
 
+def test_randomized_shapes(fa, oracle_mod):
+    # seeded random (B, H, N, D, dtype, causal, scale): ragged N everywhere, both head dims, custom scales
+    rng = np.random.default_rng(2024)
+    for _ in range(40):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 6))
+        N = int(rng.choice([1, 2, 31, 33, 64, 96, 127, 128, 191, 257, 300, 449, 640]))
+        D = int(rng.choice([64, 128]))
+        dtype = str(rng.choice(["f16", "bf16", "fp8"]))
+        causal = bool(rng.integers(0, 2))
+        scale = float(rng.choice([D ** -0.5, 0.05, 0.2]))
+        q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype, seeds=tuple(int(x) for x in rng.integers(1, 10 ** 6, 3)))
+        o, lse = run_op(fa, q, k, v, dtype, causal, "mfma", scale)
+        o64, l64 = oracle_mod.attn_fwd_f64(q, k, v, causal, scale)
+        tol = TOL_O["f16"] if dtype == "f16" else TOL_O["bf16"]
+        assert np.abs(o - o64).max() < tol, (B, H, N, D, dtype, causal, scale)
+        assert np.abs(lse - l64).max() < 1e-4, (B, H, N, D, dtype, causal, scale)
+
+
 def test_torch_custom_op_matches_sdpa(fa, oracle_mod):
     # the kernel as a torch operator, compared in-process with torch's own attention
     import torch
