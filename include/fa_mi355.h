@@ -79,6 +79,9 @@ enum fa_status {
  *  scale         softmax scale (> 0); the reference passes 1/sqrt(D) (main.mm:13)
  *  dtype/variant enums above
  *  hip_stream    hipStream_t on the current device, or NULL
+ * Inputs are expected to be finite: the matrix-core kernels are compiled without NaN handling (their
+ * own -inf mask values never meet anything that could produce one), so NaN/Inf in Q, K or V give
+ * unspecified output values (never a fault).
  */
 int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
            int B, int H, int N, int D, float scale,
