@@ -233,6 +233,47 @@ def test_randomized_shapes(fa, oracle_mod):
         assert np.abs(lse - l64).max() < 1e-4, (B, H, N, D, dtype, causal, scale)
 
 
+def test_launch_is_graph_capturable(fa, oracle_mod):
+    # the C-ABI promises no allocation / synchronisation inside the launch (HIPGUIDE guideline 9):
+    # capture forward + backward into a HIP graph, replay it on new data, compare with eager launches
+    import torch
+
+    B, H, N, D = 2, 4, 512, 64
+    q, k, v = (to_dev(x, "bf16") for x in make_qkv(oracle_mod, B, H, N, D, "bf16"))
+    do = to_dev(oracle_mod.round_to(oracle_mod.init_random(B * H * N * D, 45).reshape(B, H, N, D), "bf16"), "bf16")
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device="cuda")
+    lib = fa.load_library()
+    dq, dk, dv = (torch.empty(B, H, N, D, dtype=torch.float32, device="cuda") for _ in range(3))
+    ws = torch.empty(lib.fa_bwd_workspace_bytes(B, H, N), dtype=torch.uint8, device="cuda")
+
+    def launch(stream):
+        assert lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, D, D ** -0.5,
+                          H * N * D, N * D, 1, 2, 0, stream) == 0
+        assert lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                          dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, H, N, D, D ** -0.5, H * N * D, N * D,
+                          1, 2, stream) == 0
+
+    launch(torch.cuda.current_stream().cuda_stream)  # eager reference (also warms the module)
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in (o, lse, dq, dk, dv)]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launch(torch.cuda.current_stream().cuda_stream)
+    for t in (o, lse, dq, dk, dv):
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip((o, lse, dq, dk, dv), ref):
+        assert torch.equal(a, b)
+    q.copy_(q.flip(2))  # new inputs, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    launch(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert not torch.equal(o, ref[0])
+
+
 def test_torch_custom_op_matches_sdpa(fa, oracle_mod):
     # the kernel as a torch operator, compared in-process with torch's own attention
     import torch
