@@ -1,6 +1,7 @@
 // fa_api.hip -- the C-ABI entry points of include/fa_mi355.h.
 // Validation + dispatch only; every kernel lives in its own file.
 #include <stdarg.h>
+#include <algorithm>
 #include <stdio.h>
 #include <string.h>
 
@@ -115,6 +116,8 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
   p.scale = scale;
   p.batch_stride = batch_stride; p.head_stride = head_stride;
   p.is_causal = is_causal ? 1 : 0;
+  p.Nk = N; p.Hkv = H;
+  p.kv_batch_stride = batch_stride; p.kv_head_stride = head_stride;
   hipStream_t s = (hipStream_t)hip_stream;
   hipError_t e;
   switch (variant) {
@@ -126,6 +129,40 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)
     return fail(FA_ERR_NO_DEVICE, "fa_fwd: %s", hipGetErrorString(e));
   if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_fwd: launch failed: %s", hipGetErrorString(e));
+  return FA_OK;
+}
+
+int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse, int B, int Hq, int Hkv, int Nq, int Nk,
+              int D, float scale, long long q_batch_stride, long long q_head_stride, long long kv_batch_stride,
+              long long kv_head_stride, int is_causal, int dtype, void *hip_stream) {
+  g_err[0] = 0;
+  if (!q || !k || !v || !o) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: null tensor pointer");
+  if (B < 1 || Hq < 1 || Hkv < 1 || Nq < 1 || Nk < 1 || D < 1)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: sizes must be >= 1");
+  if (Hq % Hkv) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
+  if (is_causal && Nk < Nq)
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: causal needs Nk >= Nq (bottom-right alignment would leave empty rows)");
+  if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: scale=%g must be > 0", (double)scale);
+  if (!fa::mfma_supported(dtype, D))
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: needs the matrix-core kernel (f16/bf16/fp8, D=64|128), got dtype=%s D=%d",
+                fa_dtype_name(dtype), D);
+  const int sm = dtype == FA_DTYPE_FP8_E4M3 ? 16 : 8;
+  if (q_head_stride < (long long)Nq * D || kv_head_stride < (long long)Nk * D || (q_batch_stride % sm) || (q_head_stride % sm) ||
+      (kv_batch_stride % sm) || (kv_head_stride % sm) || (Hq > 1 && B > 1 && q_batch_stride < q_head_stride) ||
+      (Hkv > 1 && B > 1 && kv_batch_stride < kv_head_stride))
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: bad strides");
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: tensors must be 16-byte aligned");
+  if ((double)std::max(Nq, Nk) * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: one head exceeds 4 GiB");
+  fa::Params p;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
+  p.B = B; p.H = Hq; p.N = Nq; p.D = D; p.scale = scale;
+  p.batch_stride = q_batch_stride; p.head_stride = q_head_stride;
+  p.is_causal = is_causal ? 1 : 0;
+  p.Nk = Nk; p.Hkv = Hkv; p.kv_batch_stride = kv_batch_stride; p.kv_head_stride = kv_head_stride;
+  hipError_t e = fa::launch_mfma(p, dtype, (hipStream_t)hip_stream);
+  if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_fwd_ex: launch failed: %s", hipGetErrorString(e));
   return FA_OK;
 }
 

@@ -16,6 +16,9 @@ struct Params {
   float scale;
   long long batch_stride, head_stride;  // elements
   int is_causal;
+  // generalised operator (fa_fwd_ex; fa_fwd sets Nk = N, Hkv = H, kv strides = q strides):
+  int Nk = 0, Hkv = 0;                          // keys per head; key/value heads (H % Hkv == 0)
+  long long kv_batch_stride = 0, kv_head_stride = 0;
   int head_group = 0;  // internal: causal blocks are issued heaviest-first within groups of this many heads (0 = all)
 };
 

@@ -71,17 +71,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   int bh, qb;
   map_block<CAUSAL>(blockIdx.x, BH, nQ, bh, qb, p.head_group);
   const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
+  // grouped-query heads: query head h reads key/value head h / (H / Hkv); Nk keys per head.
+  // Causal with Nq != Nk is bottom-right aligned: key j visible to query i iff j <= i + coff.
+  const long long base_kv = (long long)(bh / p.H) * p.kv_batch_stride + (long long)((bh % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
+  const int coff = p.Nk - p.N;
   const int q0 = qb * BM;
   const int qw0 = q0 + wave * WM;  // first query row of this wave
   const int qrow = qw0 + r;
 
-  const unsigned head_bytes = (unsigned)p.N * GRB;
+  const unsigned head_bytes = (unsigned)p.N * GRB, kv_head_bytes = (unsigned)p.Nk * GRB;
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
       (void *)((const char *)p.q + base * GB), 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)((const char *)p.k + base * GB), 0, head_bytes, 0x00020000);
+      (void *)((const char *)p.k + base_kv * GB), 0, kv_head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
-      (void *)((const char *)p.v + base * GB), 0, head_bytes, 0x00020000);
+      (void *)((const char *)p.v + base_kv * GB), 0, kv_head_bytes, 0x00020000);
 
   // ---- Q fragments (B operand of K.Q^T): lane (r,h) holds Q[qrow][16ks+8h .. +7].
   // Rows >= N read as zero through the descriptor's range check.
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
     }
   }
 
-  const int kv_end = CAUSAL ? min(p.N, q0 + BM) : p.N;
+  const int kv_end = CAUSAL ? min(p.Nk, q0 + BM + coff) : p.Nk;
   const int nT = (kv_end + BN - 1) / BN;
 
   u32x4 kst[NCH], vst[NCH];
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 
     // whole-tile skip per wave (kernels.metal:682 with Br = 32): every key of
     // the tile is past this wave's last query row
-    const bool wave_active = !CAUSAL || (kv0 <= qw0 + WM - 1);
+    const bool wave_active = !CAUSAL || (kv0 <= qw0 + WM - 1 + coff);
     if (wave_active) {
       const lds_char *Kt = Kbuf + buf * TILE;
       const lds_char *Vt = Vbuf + buf * TILE;
@@ -248,13 +252,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
         }
       }
       // ---- mask (only on tiles that cross the diagonal or the end of the sequence)
-      const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0)) || (kv0 + BN > p.N);
+      const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk);
       if (need_mask) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
           // masked iff key > qrow (kernels.metal:748) or key >= N
-          int lim = p.N - 1 - kv0 - 32 * kb - 4 * h;
-          if (CAUSAL) lim = min(lim, qrow - kv0 - 32 * kb - 4 * h);
+          int lim = p.Nk - 1 - kv0 - 32 * kb - 4 * h;
+          if (CAUSAL) lim = min(lim, qrow + coff - kv0 - 32 * kb - 4 * h);
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int kpart = (i & 3) + 8 * (i >> 2);
@@ -415,7 +419,7 @@ static hipError_t launch_one(const Params &p, hipStream_t s) {
   // long sequences, sized so that one XCD's share of K+V stays under 8 MiB (floor: 16 heads).
   {
     const int BH = p.B * p.H;
-    const double kv_bytes = 2.0 * p.N * D * (std::is_same<Tag, FP8>::value ? 1 : 2);
+    const double kv_bytes = 2.0 * p.Nk * D * (std::is_same<Tag, FP8>::value ? 1 : 2);
     int per_xcd = (int)(8.0 * 1024 * 1024 / kv_bytes);
     if (per_xcd < 2) per_xcd = 2;
     int hg = 8 * per_xcd;

@@ -67,6 +67,8 @@ def flash_attention_forward(
 ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Launch the gfx950 kernel on the current torch stream (asynchronous)."""
     lib = load_library()
+    if q.dim() == 4 and k.dim() == 4 and k.shape == v.shape and q.shape != k.shape:
+        return _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream)  # GQA / Nq != Nk
     if q.dim() != 4 or q.shape != k.shape or q.shape != v.shape:
         raise ValueError(f"q, k, v must share one [B,H,N,D] shape, got {tuple(q.shape)} {tuple(k.shape)} {tuple(v.shape)}")
     if not (q.is_cuda and k.is_cuda and v.is_cuda):
@@ -97,6 +99,39 @@ def flash_attention_forward(
                         lse.data_ptr() if lse is not None else None,
                         B, H, N, D, float(scale), bs, hs, int(bool(is_causal)),
                         fa_dtype, VARIANTS[variant], stream)
+    if st != 0:
+        raise FaError(st, lib.fa_last_error().decode())
+    return out, lse
+
+
+def _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream):
+    """Generalised call (include/fa_mi355.h fa_fwd_ex): q [B,Hq,Nq,D], k/v [B,Hkv,Nk,D], Hq % Hkv == 0,
+    causal bottom-right aligned (key j visible to query i iff j <= i + Nk - Nq)."""
+    B, Hq, Nq, D = q.shape
+    Bk, Hkv, Nk, Dk = k.shape
+    if Bk != B or Dk != D or Hq % Hkv:
+        raise ValueError(f"incompatible shapes q {tuple(q.shape)} k/v {tuple(k.shape)}")
+    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+        raise RuntimeError("flash_attention_forward needs device tensors: there is no CPU path")
+    if q.dtype not in _TORCH2FA or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError(f"unsupported / mixed dtypes {q.dtype} {k.dtype} {v.dtype}")
+    qbs, qhs = _strides(q)
+    kbs, khs = _strides(k)
+    if _strides(v) != (kbs, khs):
+        raise ValueError("k and v must share batch/head strides")
+    fa_dtype = _TORCH2FA[q.dtype]
+    out_dtype = torch.bfloat16 if fa_dtype == 3 else q.dtype
+    if out is None:
+        out = torch.empty_strided((B, Hq, Nq, D), q.stride(), dtype=out_dtype, device=q.device)
+    if return_lse and lse is None:
+        lse = torch.empty((B, Hq, Nq), dtype=torch.float32, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if stream is None:
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+    with torch.cuda.device(q.device):
+        st = lib.fa_fwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+                           B, Hq, Hkv, Nq, Nk, D, float(scale), qbs, qhs, kbs, khs, int(bool(is_causal)), fa_dtype, stream)
     if st != 0:
         raise FaError(st, lib.fa_last_error().decode())
     return out, lse

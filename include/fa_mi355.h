@@ -89,6 +89,21 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
            int is_causal, int dtype, int variant, void *hip_stream);
 
 /*
+ * Generalised forward (scope row f3; not in the reference, whose operator is square and multi-head):
+ * grouped-query / multi-query heads and a key length different from the query length.
+ *   q, o  [B, Hq, Nq, D] with q_batch_stride / q_head_stride;  k, v  [B, Hkv, Nk, D] with kv strides
+ *   query head h attends to key/value head h / (Hq / Hkv)   (Hq % Hkv == 0)
+ *   causal is bottom-right aligned: key j is visible to query i iff j <= i + (Nk - Nq); needs Nk >= Nq
+ *   lse [B, Hq, Nq]. Matrix-core kernel only (f16 / bf16 / fp8 inputs, D = 64 or 128).
+ * With Hkv = Hq, Nk = Nq and equal strides this is exactly fa_fwd(..., FA_VARIANT_MFMA).
+ */
+int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse,
+              int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
+              long long q_batch_stride, long long q_head_stride,
+              long long kv_batch_stride, long long kv_head_stride,
+              int is_causal, int dtype, void *hip_stream);
+
+/*
  * Backward of the operator (row f1 of the scope table): the reference binds it as
  * flash_attention_backward_kernel, /root/reference/kernels.metal:905-921, host side
  * /root/reference/main.mm:1015-1058:

@@ -50,6 +50,7 @@ def _load() -> ctypes.CDLL:
                                         c_float, c_longlong, c_longlong, c_int, c_int]
     lib.oracle_attn_rows_f64.argtypes = [_fp, _fp, _fp, _dp, _dp, c_int, c_int, c_float, c_int,
                                          POINTER(c_int), c_int, c_int]
+    lib.oracle_attn_fwd_ex_f64.argtypes = [_fp, _fp, _fp, _dp, _dp, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int]
     lib.oracle_attn_bwd_f64.argtypes = [_fp, _fp, _fp, _fp, _dp, _dp, _dp, c_int, c_int, c_int, c_int, c_float, c_int, c_int]
     for name in ("oracle_round_f16", "oracle_round_bf16", "oracle_round_fp8_e4m3"):
         getattr(lib, name).argtypes = [_fp, c_longlong]
@@ -150,6 +151,21 @@ def attn_rows_f64(q, k, v, rows, is_causal: bool, scale: float | None = None, th
     lse = np.empty(len(rows), dtype=np.float64)
     lib().oracle_attn_rows_f64(_f(q), _f(k), _f(v), _d(o), _d(lse), N, D, scale, int(is_causal),
                                rows.ctypes.data_as(POINTER(c_int)), len(rows), threads)
+    return o, lse
+
+
+def attn_fwd_ex_f64(q, k, v, is_causal: bool, scale: float | None = None, threads: int = 0):
+    """Generalised fp64 (O, LSE): q [B,Hq,Nq,D], k/v [B,Hkv,Nk,D] (grouped-query heads, Nq != Nk)."""
+    B, Hq, Nq, D = q.shape
+    _, Hkv, Nk, _ = k.shape
+    assert Hq % Hkv == 0 and v.shape == k.shape
+    if scale is None:
+        scale = float(np.float32(1.0) / np.float32(np.sqrt(D)))
+    if threads <= 0:
+        threads = max_threads()
+    o = np.empty(q.shape, dtype=np.float64)
+    lse = np.empty((B, Hq, Nq), dtype=np.float64)
+    lib().oracle_attn_fwd_ex_f64(_f(q), _f(k), _f(v), _d(o), _d(lse), B, Hq, Hkv, Nq, Nk, D, scale, int(is_causal), threads)
     return o, lse
 
 

@@ -297,6 +297,56 @@ void oracle_attn_rows_f64(const float *q, const float *k, const float *v,
 }
 
 /* ------------------------------------------------------------------------- */
+/* generalised operator (scope row f3), fp64: grouped-query heads and Nq != Nk.  */
+/* Query head h reads key/value head h / (Hq/Hkv). Causal with Nq != Nk is       */
+/* bottom-right aligned: key j is visible to query i iff j <= i + (Nk - Nq)       */
+/* (for Nq == Nk this is kernels.metal:748). Not in the reference: unpinned.      */
+/* q,o: [B,Hq,Nq,D]; k,v: [B,Hkv,Nk,D]; lse: [B,Hq,Nq]; all contiguous.           */
+/* ------------------------------------------------------------------------- */
+void oracle_attn_fwd_ex_f64(const float *q, const float *k, const float *v, double *o, double *lse,
+                            int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
+                            int is_causal, int threads) {
+  if (threads < 1) threads = 1;
+  const int group = Hq / Hkv, off = Nk - Nq;
+  const long long rows = (long long)B * Hq * Nq;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(threads)
+#endif
+  {
+    double *scores = (double *)malloc(sizeof(double) * (size_t)(Nk > 0 ? Nk : 1));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (long long r = 0; r < rows; ++r) {
+      const long long bh = r / Nq;
+      const int i = (int)(r % Nq);
+      const long long b = bh / Hq, h = bh % Hq, hk = h / group;
+      const float *qi = q + ((b * Hq + h) * Nq + i) * (long long)D;
+      const float *K = k + (b * Hkv + hk) * (long long)Nk * D, *V = v + (b * Hkv + hk) * (long long)Nk * D;
+      int jn = is_causal ? i + off + 1 : Nk;
+      if (jn > Nk) jn = Nk;
+      double m = -INFINITY, l = 0.0;
+      for (int j = 0; j < jn; ++j) {
+        double sc = 0.0;
+        for (int d = 0; d < D; ++d) sc += (double)qi[d] * (double)K[(long long)j * D + d];
+        sc *= (double)scale;
+        scores[j] = sc;
+        if (sc > m) m = sc;
+      }
+      for (int j = 0; j < jn; ++j) { scores[j] = exp(scores[j] - m); l += scores[j]; }
+      double *oi = o + ((b * Hq + h) * Nq + i) * (long long)D;
+      for (int d = 0; d < D; ++d) {
+        double acc = 0.0;
+        for (int j = 0; j < jn; ++j) acc += scores[j] * (double)V[(long long)j * D + d];
+        oi[d] = jn > 0 ? acc / l : 0.0;
+      }
+      if (lse) lse[bh * Nq + i] = jn > 0 ? m + log(l) : -INFINITY;
+    }
+    free(scores);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* backward (fp64): dQ, dK, dV of the operator for upstream gradient dO.        */
 /* Math of /root/reference/kernels.metal:905-1265 (D_i at :983-990, P = exp(S*scale - L_i)  */
 /* at :1082-1089, dS = P*(dP - D_i)*scale at :1160-1169). The reference's own CPU check of   */

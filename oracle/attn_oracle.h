@@ -70,6 +70,13 @@ void oracle_attn_rows_f64(const float *q, const float *k, const float *v,
                           int N, int D, float scale, int is_causal,
                           const int *rows, int nrows, int threads);
 
+/* Generalised operator in fp64: grouped-query heads (Hq % Hkv == 0) and Nq != Nk with bottom-right
+ * causal alignment (key j visible to query i iff j <= i + Nk - Nq). Contiguous q,o [B,Hq,Nq,D],
+ * k,v [B,Hkv,Nk,D], lse [B,Hq,Nq]. Not in the reference: unpinned. */
+void oracle_attn_fwd_ex_f64(const float *q, const float *k, const float *v, double *o, double *lse,
+                            int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
+                            int is_causal, int threads);
+
 /* fp64 gradients of the operator over contiguous [B,H,N,D] (kernels.metal:905-1265 math).
  * Backward parity is unpinned by the reference (its CPU check is broken, main.mm:1100-1101). */
 void oracle_attn_bwd_f64(const float *q, const float *k, const float *v, const float *d_o,

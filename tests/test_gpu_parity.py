@@ -233,6 +233,37 @@ def test_randomized_shapes(fa, oracle_mod):
         assert np.abs(lse - l64).max() < 1e-4, (B, H, N, D, dtype, causal, scale)
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
+    # scope row f3: grouped/multi-query heads and Nq != Nk (bottom-right causal alignment), vs the fp64 oracle
+    import torch
+
+    rng = np.random.default_rng(11)
+    cases = [  # B, Hq, Hkv, Nq, Nk, D, causal
+        (2, 8, 2, 200, 200, 64, True), (1, 8, 1, 130, 130, 64, False), (2, 4, 4, 64, 300, 64, True),
+        (1, 6, 3, 1, 257, 64, True), (1, 4, 2, 100, 37, 64, False), (1, 8, 2, 129, 512, 128, True),
+        (1, 2, 1, 77, 77, 128, True), (1, 16, 4, 33, 1000, 64, True)]
+    for (B, Hq, Hkv, Nq, Nk, D, causal) in cases:
+        q = oracle_mod.round_to(oracle_mod.init_random(B * Hq * Nq * D, int(rng.integers(1, 1 << 20))).reshape(B, Hq, Nq, D), dtype)
+        k = oracle_mod.round_to(oracle_mod.init_random(B * Hkv * Nk * D, int(rng.integers(1, 1 << 20))).reshape(B, Hkv, Nk, D), dtype)
+        v = oracle_mod.round_to(oracle_mod.init_random(B * Hkv * Nk * D, int(rng.integers(1, 1 << 20))).reshape(B, Hkv, Nk, D), dtype)
+        qd, kd, vd = (to_dev(x, dtype) for x in (q, k, v))
+        o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal)
+        torch.cuda.synchronize()
+        o64, l64 = oracle_mod.attn_fwd_ex_f64(q, k, v, causal)
+        assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype], (B, Hq, Hkv, Nq, Nk, D, causal)
+        assert np.abs(lse.cpu().numpy() - l64).max() < 1e-4
+        if Nq == Nk:  # GQA == MHA on repeated K/V heads, bit for bit
+            g = Hq // Hkv
+            o2, l2 = fa.flash_attention_forward(qd, kd.repeat_interleave(g, 1).contiguous(), vd.repeat_interleave(g, 1).contiguous(), is_causal=causal)
+            assert torch.equal(o, o2) and torch.equal(lse, l2)
+    x = to_dev(np.zeros((1, 4, 64, 64), np.float32), dtype)
+    with pytest.raises(fa.FaError):  # causal with fewer keys than queries would leave empty rows: refused
+        fa.flash_attention_forward(x, x[:, :2, :32].contiguous(), x[:, :2, :32].contiguous(), is_causal=True)
+    with pytest.raises(ValueError):  # Hq not a multiple of Hkv
+        fa.flash_attention_forward(x, x[:, :3].contiguous(), x[:, :3].contiguous())
+
+
 def test_launch_is_graph_capturable(fa, oracle_mod):
     # the C-ABI promises no allocation / synchronisation inside the launch (HIPGUIDE guideline 9):
     # capture forward + backward into a HIP graph, replay it on new data, compare with eager launches

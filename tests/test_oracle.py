@@ -135,3 +135,22 @@ def test_rounding_helpers_match_torch(oracle_mod):
         fin = np.isfinite(theirs) & (np.abs(x) <= 448.0)  # torch's cast does not saturate; ours does
         np.testing.assert_array_equal(ours[fin], theirs[fin])
         assert np.all(np.abs(ours[np.abs(x) > 448.0]) == 448.0)
+
+
+def test_generalised_oracle_reduces_to_the_operator(oracle_mod):
+    # fa_fwd_ex semantics (row f3): with Hkv == Hq and Nk == Nq it is the operator; GQA == repeated heads
+    B, H, N, D = 2, 4, 50, 64
+    q, k, v = (oracle_mod.init_random(B * H * N * D, s).reshape(B, H, N, D) for s in (1, 2, 3))
+    for causal in (False, True):
+        a, la = oracle_mod.attn_fwd_f64(q, k, v, causal)
+        b, lb = oracle_mod.attn_fwd_ex_f64(q, k, v, causal)
+        assert np.array_equal(a, b) and np.array_equal(la, lb)
+        kk, vv = np.ascontiguousarray(k[:, :2]), np.ascontiguousarray(v[:, :2])
+        o1, _ = oracle_mod.attn_fwd_ex_f64(q, kk, vv, causal)
+        o2, _ = oracle_mod.attn_fwd_f64(q, np.ascontiguousarray(np.repeat(kk, 2, 1)), np.ascontiguousarray(np.repeat(vv, 2, 1)), causal)
+        assert np.array_equal(o1, o2)
+    # bottom-right alignment: a single query against Nk keys sees all of them under the causal mask
+    q1 = np.ascontiguousarray(q[:, :, :1])
+    oc, _ = oracle_mod.attn_fwd_ex_f64(q1, k, v, True)
+    on, _ = oracle_mod.attn_fwd_ex_f64(q1, k, v, False)
+    assert np.array_equal(oc, on)
