@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bwd_dkdv_kernel(BwdParams p) {
   lds_char *QT = smem + 2 * BTILE;    // [2] Q tile, transposed-read image
   lds_char *OR_ = smem + 4 * BTILE;   // [2] dO tile, row-read image
   lds_char *OT = smem + 6 * BTILE;    // [2] dO tile, transposed-read image
-  lds_char *ROWS = smem + 8 * BTILE;  // [2][2][64] floats: lse*log2e, delta of the tile's query rows
+  lds_char *ROWS = smem + 8 * BTILE;  // [2][2][64] floats: lse*log2e, delta*scale of the tile's query rows
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bwd_dkdv_kernel(BwdParams p) {
   const int t_begin = CAUSAL ? k0 / BN : 0;
 
   u32x4 qst[NCH], ost[NCH];
-  float rowv = 0.0f;  // threads 0..63: lse*log2e of row tid; 64..127: delta of row tid-64
+  float rowv = 0.0f;  // threads 0..63: lse*log2e of row tid; 64..127: delta*scale of row tid-64
   auto stage_load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void bwd_dkdv_kernel(BwdParams p) {
     if (tid < 128) {
       const int qi = t * BN + (tid & 63);
       if (tid < 64) rowv = qi < p.N ? p.lse[(long long)bh * p.N + qi] * LOG2E : INFINITY;  // p = 0 past N
-      else rowv = qi < p.N ? p.delta[(long long)bh * p.N + qi] : 0.0f;
+      else rowv = qi < p.N ? p.delta[(long long)bh * p.N + qi] * p.scale : 0.0f;  // delta*scale: dS = P*fma(dP, scale, -delta*scale)
     }
   };
   auto stage_write = [&](int buf) {
@@ -347,6 +347,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void bwd_dkdv_kernel(BwdParams p) {
       }
       // registers 4g..4g+3 of block qb are query rows 32qb + 8g + 4h + 0..3 of the tile
       vec8 pf[2][2], df[2][2];
+      // only tiles that cross the diagonal for this wave need the per-element mask (wave-uniform)
+      const bool need_mask = CAUSAL && (qt0 < kw0 + WM - 1);
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
@@ -362,9 +364,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void bwd_dkdv_kernel(BwdParams p) {
             const unsigned lw = l4[e], dw = d4[e];
             const float lse_q = __builtin_bit_cast(float, lw), delta_q = __builtin_bit_cast(float, dw);
             float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][i], c2, -lse_q));
-            if (CAUSAL && (qt0 + ql + e < krow)) pv = 0.0f;  // key > query (kernels.metal:748)
+            if (need_mask && (qt0 + ql + e < krow)) pv = 0.0f;  // key > query (kernels.metal:748)
             s[qb][i] = pv;
-            dp[qb][i] = pv * p.scale * (dp[qb][i] - delta_q);
+            dp[qb][i] = pv * __builtin_fmaf(dp[qb][i], p.scale, -delta_q);  // delta_q already carries scale
           }
         }
 #pragma unroll

@@ -426,7 +426,8 @@ static hipError_t launch_one(const Params &p, hipStream_t s) {
     while (hg < BH && (BH % hg) != 0) hg += 8;
     pp.head_group = (BH % 8 == 0 && hg < BH) ? hg : 0;
   }
-  if (const char *e = getenv("FA_HEAD_GROUP")) pp.head_group = atoi(e);  // scheduling experiments
+  static const int env_head_group = [] { const char *e = getenv("FA_HEAD_GROUP"); return e ? atoi(e) : -1; }();
+  if (env_head_group >= 0) pp.head_group = env_head_group;  // scheduling experiments only (read once)
   hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
   return hipGetLastError();
 }
@@ -440,7 +441,11 @@ static hipError_t launch_dt(const Params &p, hipStream_t s) {
 hipError_t launch_mfma_pipe_d64(const Params &p, int dtype, hipStream_t s);  // fa_mfma_pipe_kernel.hip
 
 hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s) {
-  if (p.D == 64 && dtype != FA_DTYPE_FP8_E4M3 && getenv("FA_MFMA_PIPE")) return launch_mfma_pipe_d64(p, dtype, s);  // experimental software-pipelined kernel
+  // experimental software-pipelined head_dim-64 kernel: opt-in, square multi-head problems only
+  static const bool env_pipe = getenv("FA_MFMA_PIPE") != nullptr;
+  if (env_pipe && p.D == 64 && dtype != FA_DTYPE_FP8_E4M3 && p.Nk == p.N && p.Hkv == p.H &&
+      p.kv_batch_stride == p.batch_stride && p.kv_head_stride == p.head_stride)
+    return launch_mfma_pipe_d64(p, dtype, s);  // experimental software-pipelined kernel
   if (dtype == FA_DTYPE_FP8_E4M3) return launch_dt<FP8>(p, s);
   return dtype == FA_DTYPE_F16 ? launch_dt<F16>(p, s) : launch_dt<BF16>(p, s);
 }
