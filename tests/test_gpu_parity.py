@@ -264,6 +264,30 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
         fa.flash_attention_forward(x, x[:, :3].contiguous(), x[:, :3].contiguous())
 
 
+def test_reentrant_across_streams(fa, oracle_mod):
+    # include/fa_mi355.h: "no state, re-entrant across devices/streams": two different problems launched
+    # concurrently on two streams give the same bits as when run alone
+    import torch
+
+    a = [to_dev(x, "bf16") for x in make_qkv(oracle_mod, 2, 8, 1024, 64, "bf16", seeds=(1, 2, 3))]
+    b = [to_dev(x, "f16") for x in make_qkv(oracle_mod, 1, 4, 777, 128, "f16", seeds=(4, 5, 6))]
+    ra = fa.flash_attention_forward(*a, is_causal=True)
+    rb = fa.flash_attention_forward(*b, is_causal=False)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            oa = fa.flash_attention_forward(*a, is_causal=True)
+        with torch.cuda.stream(s2):
+            ob = fa.flash_attention_forward(*b, is_causal=False)
+        outs.append((oa, ob))
+    torch.cuda.synchronize()
+    for oa, ob in outs:
+        assert torch.equal(oa[0], ra[0]) and torch.equal(oa[1], ra[1])
+        assert torch.equal(ob[0], rb[0]) and torch.equal(ob[1], rb[1])
+
+
 def test_launch_is_graph_capturable(fa, oracle_mod):
     # the C-ABI promises no allocation / synchronisation inside the launch (HIPGUIDE guideline 9):
     # capture forward + backward into a HIP graph, replay it on new data, compare with eager launches
