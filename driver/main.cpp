@@ -427,20 +427,26 @@ static void run_configs(const Options &opt, std::ofstream &ext) {
 }
 
 // ---- CPU timing table on this host (a baseline, not the target) -------------------------------
-static void run_cpu_table(const Options &opt) {
+static void run_cpu_table(const Options &opt, std::ofstream &ext) {
   const int D = 64;
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const int T = opt.cpu_threads > 0 ? opt.cpu_threads : (int)hw;
   std::cout << "\n--- CPU baseline on this host (" << hw << " hardware threads; g++-style -O3, no fast-math) ---\n";
   std::cout << "kind,N,causal,threads,seconds,GFLOPS" << std::endl;
   auto now = [] { return std::chrono::steady_clock::now(); };
-  for (int n : {128, 256, 512}) {  // reference loop structure, single thread (main.mm:128-159 is O(N^2 D^2))
+  auto ext_cpu = [&](int n, const char *kind, int causal, int bh, int threads, double seconds, double gflops) {
+    if (!ext.is_open()) return;  // same columns as the GPU rows; `devices` carries the thread count, median_ms the wall time
+    ext << n << "," << kind << ",f32," << causal << ",1," << bh << "," << D << "," << threads << "," << seconds * 1e3 << ","
+        << seconds * 1e3 << "," << gflops / 1e3 << ",,\n";
+  };
+  for (int n : {128, 256, 512, 1024}) {  // reference loop structure, single thread (main.mm:128-159 is O(N^2 D^2))
     std::vector<float> x((size_t)n * D), o(x.size());
     cpu::init_random(x.data(), x.size(), 42);
     auto t0 = now();
     cpu::attention_reference_structure(x.data(), x.data(), x.data(), o.data(), n, D, 0.125f);
     const double s = std::chrono::duration<double>(now() - t0).count();
     std::cout << "reference-structure," << n << ",0,1," << s << "," << 4.0 * n * n * D / s / 1e9 << std::endl;
+    ext_cpu(n, "cpu_reference_structure", 0, 1, 1, s, 4.0 * n * n * D / s / 1e9);
   }
   for (int n : {1024, 4096}) {
     for (int causal = 0; causal < 2; ++causal) {
@@ -453,6 +459,7 @@ static void run_cpu_table(const Options &opt) {
         const double s = std::chrono::duration<double>(now() - t0).count();
         std::cout << "hoisted," << n << "," << causal << "," << threads << "," << s << ","
                   << fa_algorithmic_flops(1, BH, n, D, causal) / s / 1e9 << std::endl;
+        ext_cpu(n, "cpu_hoisted", causal, BH, threads, s, fa_algorithmic_flops(1, BH, n, D, causal) / s / 1e9);
         if (T == 1) break;
       }
     }
@@ -506,7 +513,7 @@ int main(int argc, char **argv) {
   if (opt.sweep) run_sweep(opt, ext);
   if (opt.high_occ) run_high_occupancy(opt, ext);
   if (opt.configs) run_configs(opt, ext);
-  if (opt.cpu_table) run_cpu_table(opt);
+  if (opt.cpu_table) run_cpu_table(opt, ext);
   if (g_failures) std::cout << "\n" << g_failures << " check(s) FAILED" << std::endl;
   return g_failures ? 1 : 0;
 }
