@@ -257,6 +257,15 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
             g = Hq // Hkv
             o2, l2 = fa.flash_attention_forward(qd, kd.repeat_interleave(g, 1).contiguous(), vd.repeat_interleave(g, 1).contiguous(), is_causal=causal)
             assert torch.equal(o, o2) and torch.equal(lse, l2)
+    if dtype == "bf16":  # the same generalised path with fp8 (e4m3) inputs: bit-equal to bf16 on the same values
+        q = oracle_mod.round_to(oracle_mod.init_random(2 * 8 * 96 * 64, 5).reshape(2, 8, 96, 64) * 2, "fp8")
+        k = oracle_mod.round_to(oracle_mod.init_random(2 * 2 * 333 * 64, 6).reshape(2, 2, 333, 64) * 2, "fp8")
+        v = oracle_mod.round_to(oracle_mod.init_random(2 * 2 * 333 * 64, 7).reshape(2, 2, 333, 64) * 2, "fp8")
+        o8, l8 = fa.flash_attention_forward(to_dev(q, "fp8"), to_dev(k, "fp8"), to_dev(v, "fp8"), is_causal=True)
+        ob, lb = fa.flash_attention_forward(to_dev(q, "bf16"), to_dev(k, "bf16"), to_dev(v, "bf16"), is_causal=True)
+        assert torch.equal(o8, ob) and torch.equal(l8, lb)
+        o64, _ = oracle_mod.attn_fwd_ex_f64(q, k, v, True)
+        assert np.abs(o8.float().cpu().numpy() - o64).max() < TOL_O["bf16"] * 2
     x = to_dev(np.zeros((1, 4, 64, 64), np.float32), dtype)
     with pytest.raises(fa.FaError):  # causal with fewer keys than queries would leave empty rows: refused
         fa.flash_attention_forward(x, x[:, :2, :32].contiguous(), x[:, :2, :32].contiguous(), is_causal=True)
