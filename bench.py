@@ -4,6 +4,10 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work. Typed without a launcher and with N > 1, this process never touches the GPU: it
+spawns N fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set before they import torch),
+waits for them and relays rank 0's JSON line -- no exec of a GPU-initialised process.
+
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
 seqlen=4096, head_dim=64, batch=4, heads=16, bf16, is_causal=true PER GPU.
 The (batch, head) slices of the global [4*N_gpus, 16, 4096, 64] problem are
@@ -13,16 +17,21 @@ fa_fwd() launch over the rank's shard with Q/K/V already resident in HBM.
 
 Prints ONE JSON line on rank 0. `value` = algorithmic FLOPs of all ranks' steps
 / max-over-ranks wall time of the K timed steps (barrier + synchronize on both
-sides). `roofline.achieved` is measured with HIP events on the launch stream
-over the same K launches (events bracket blocks of 10 launches). `cpu_baseline` times the reference's own
-CPU loop (oracle/_ref, kind "reference") or our C port of it (kind "port") on
-the host cores, rank 0 at N=1 only, on a bounded sample.
+sides). Before the W warm-up steps the GPU is additionally warmed BY TIME (>= WARM_MS of
+back-to-back launches): a handful of 0.1 ms launches ends before the clocks have settled, and the
+timed region would measure the ramp. `roofline.achieved` is measured with HIP events on the launch
+stream over the same K launches (events bracket blocks of 10 launches). `cpu_baseline` times the
+reference's own CPU loop (oracle/_ref, kind "reference") or our C port of it (kind "port") on
+the host cores, rank 0 at N=1 only, on a bounded sample. `c4_slice` is BASELINE configs[3]'s
+per-GPU shard (32 (batch,head) slices of seqlen 16384, head_dim 128): with --gpus 8 the ranks
+together run config 4 itself.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -35,13 +44,13 @@ DTYPE = "bf16"
 CAUSAL = True
 PEAK_TFLOPS_BF16 = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16/f16
 PEAK_HBM_GBS = 8000.0      # 8 TB/s spec
+WARM_MS = 300.0            # time-based warm-up in front of the counted warm-up steps
+C4_SLICES, C4_N, C4_D = 32, 16384, 128  # BASELINE configs[3] per GPU: 8*32 heads over 8 GPUs
 
 
 def cpu_baseline(target_s: float = 15.0) -> dict:
     """Time the CPU path on a bounded sample of the workload: whole heads of
     N=4096, D=64, causal, fp32 -- the reference's loop at /root/reference/main.mm:551-578."""
-    import numpy as np
-
     import oracle  # test infrastructure: used here ONLY as the timed CPU baseline
 
     q = oracle.init_random(N * D, 42).reshape(N, D)
@@ -75,30 +84,81 @@ def cpu_baseline(target_s: float = 15.0) -> dict:
     }
 
 
-def main() -> None:
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` typed without a launcher: start N fresh child processes, one per GPU.
+    The parent imports neither torch nor the kernel library, so nothing here has initialised a GPU."""
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                FA_BENCH_CHILD="1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def timed_launches(torch, stream, step, steps, block=10):
+    """K launches, HIP events on the launch stream around blocks of `block` (an event pair around every
+    single launch puts a bubble between kernels). Returns (wall seconds incl. final sync handled by caller's
+    barrier, per-launch ms sorted, total ms)."""
+    blocks = [(i, min(i + block, steps)) for i in range(0, steps, block)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in blocks]
+    for (lo_i, hi_i), (a, b) in zip(blocks, evs):
+        a.record(stream)
+        for _ in range(lo_i, hi_i):
+            step()
+        b.record(stream)
+    return blocks, evs
+
+
+def warm_by_time(torch, dev, step, ms=WARM_MS):
+    """Launch back-to-back until `ms` of GPU time has passed (clock ramp + first-touch of caches/TLBs)."""
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(dev)
+        n += 20
+    return n
+
+
+def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-c4", action="store_true")
+    ap.add_argument("--cpu-gloo-rehearsal", action="store_true",
+                    help="rank plumbing only, on CPU over gloo (tests): no kernel is launched, no throughput is claimed")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)
 
     import torch
 
-    import flash_attention_metal_amd as fa
-
     from flash_attention_metal_amd import ranks
+
+    if args.cpu_gloo_rehearsal:
+        return rehearsal(args, ranks)
+
+    import flash_attention_metal_amd as fa
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the attention operator has no CPU path")
     fa.load_library()  # fail loudly if the HIP library is missing
     info = ranks.init_ranks(use_gpu=True)  # backend "nccl" (= RCCL): control plane only (barrier + max/sum of scalars)
     rank, local_rank, world = info.rank, info.local_rank, info.world
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -118,20 +178,12 @@ def main() -> None:
     def barrier():
         ranks.barrier(info, dev)
 
+    warm_launches = warm_by_time(torch, dev, step)
     for _ in range(args.warmup):
         step()
     barrier()
-    # HIP events on the launch stream bracket blocks of EV_BLOCK consecutive launches of the timed region
-    # (an event pair around every single launch puts a bubble between kernels); per-launch time = block / size
-    EV_BLOCK = 10
-    blocks = [(i, min(i + EV_BLOCK, args.steps)) for i in range(0, args.steps, EV_BLOCK)]
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in blocks]
     t0 = time.perf_counter()
-    for (lo_i, hi_i), (a, b) in zip(blocks, evs):
-        a.record(stream)
-        for _ in range(lo_i, hi_i):
-            step()
-        b.record(stream)
+    blocks, evs = timed_launches(torch, stream, step, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     kern_ms = sorted(a.elapsed_time(b) / (hi_i - lo_i) for (lo_i, hi_i), (a, b) in zip(blocks, evs))
@@ -141,14 +193,17 @@ def main() -> None:
     flops_per_s, elapsed = ranks.aggregate_throughput(info, flops_step_rank * args.steps, elapsed, dev)
     value = flops_per_s / 1e12
 
+    c4 = None if args.no_c4 else c4_slice(fa, torch, ranks, info, dev)
+
     if rank == 0:
         avg_ms = launches_total / args.steps  # average launch duration over the K timed launches
         achieved = flops_step_rank / (avg_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC pass result, if one was recorded
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # result of the separate rocprofv3 --pmc passes
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic, traffic_src = tj.get("bytes_per_launch"), tj.get("source")
             except Exception:
                 traffic = None
         out = {
@@ -168,20 +223,71 @@ def main() -> None:
                                    "is_causal=true per GPU",
                        "batch_per_gpu": B_PER_GPU, "heads": H, "seq_len": N, "head_dim": D, "is_causal": CAUSAL,
                        "sharding": f"(batch,head) slices block-distributed over {world} rank(s), no collective",
-                       "flops_per_step_per_gpu": flops_step_rank, "bytes_per_step_per_gpu": bytes_step_rank},
+                       "flops_per_step_per_gpu": flops_step_rank, "bytes_per_step_per_gpu": bytes_step_rank,
+                       "time_warmup_launches": warm_launches},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS_BF16,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_BF16, 4), "traffic": traffic,
-                         "kernel": "fa::fwd_mfma_kernel<fa::BF16, 64, true>",
+                         "traffic_source": traffic_src or "none recorded",
+                         "kernel": fa.forward_kernel_name(DTYPE, D, CAUSAL),
                          "kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 5),
                          "kernel_ms_min": round(kern_ms[0], 5),
                          "hbm_frac": round(bytes_step_rank / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
         }
+        if c4 is not None:
+            out["c4_slice"] = c4
         if world == 1 and not args.no_sweep:
             out["sweep"] = sweep(fa, torch, dev)
+            at = [r for r in out["sweep"] if r["seqlen"] == N]
+            if at:  # the sweep's N=4096 row is the same workload: a ratio far from 1 means the timed region ramped
+                out["sweep_vs_value"] = round(at[0]["tflops"] / value, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     ranks.finalize(info)
+    return 0
+
+
+def c4_slice(fa, torch, ranks, info, dev, iters=10):
+    """BASELINE configs[3] per GPU: 32 (batch,head) slices of seqlen 16384, head_dim 128, bf16 causal.
+    With 8 ranks the job is config 4 itself (8*32 heads sharded by (batch, head), no collective)."""
+    g = torch.Generator(device=dev).manual_seed(7000 + info.rank)
+    mk = lambda: (torch.rand(1, C4_SLICES, C4_N, C4_D, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)  # noqa: E731
+    q, k, v = mk(), mk(), mk()
+    o = torch.empty_like(q)
+    lse = torch.empty(1, C4_SLICES, C4_N, dtype=torch.float32, device=dev)
+
+    def step():
+        fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+
+    for _ in range(3):
+        step()
+    ranks.barrier(info, dev)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    ranks.barrier(info, dev)
+    el = time.perf_counter() - t0
+    fl = fa.algorithmic_flops(1, C4_SLICES, C4_N, C4_D, True)
+    per_s, worst = ranks.aggregate_throughput(info, fl * iters, el, dev)
+    return {"workload": f"BASELINE.json configs[3] shard: {C4_SLICES} slices/GPU x {info.world} GPU(s), seqlen={C4_N}, "
+                        f"head_dim={C4_D}, bf16, causal",
+            "tflops_total": round(per_s / 1e12, 2), "ms_per_step": round(worst / iters * 1e3, 4),
+            "mfma_frac": round(per_s / 1e12 / (PEAK_TFLOPS_BF16 * info.world), 4), "steps": iters}
+
+
+def rehearsal(args, ranks) -> int:
+    """The N>1 control path on CPU (gloo): rank discovery, sharding, barrier and the max/sum reductions
+    with the real launcher/spawner in front -- what tests/test_sharding.py drives. No kernel runs."""
+    info = ranks.init_ranks(use_gpu=False)
+    lo, hi = ranks.my_slices(info, B_PER_GPU * H)
+    ranks.barrier(info)
+    units = float(hi - lo) * args.steps
+    per_s, worst = ranks.aggregate_throughput(info, units, 0.001 * (info.rank + 1))
+    if info.rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": info.world, "backend": info.backend, "slices_rank0": [lo, hi],
+                          "slices_total": B_PER_GPU * H * info.world, "units_per_s": per_s, "worst_s": worst}), flush=True)
+    ranks.finalize(info)
+    return 0
 
 
 def sweep(fa, torch, dev):
@@ -212,4 +318,4 @@ def sweep(fa, torch, dev):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -17,6 +17,7 @@ from .ops import (  # noqa: F401
     algorithmic_flops,
     flash_attention_backward,
     flash_attention_forward,
+    forward_kernel_name,
     supported,
 )
 from .shard import shard_heads  # noqa: F401

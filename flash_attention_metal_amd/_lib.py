@@ -21,6 +21,8 @@ SYMBOLS = {
     "fa_bwd_algorithmic_flops": (c_double, [c_int, c_int, c_int, c_int, c_int]),
     "fa_supported": (c_int, [c_int, c_int, c_int]),
     "fa_resolve_variant": (c_int, [c_int, c_int]),
+    "fa_resolve_variant_for": (c_int, [c_int] * 6),
+    "fa_fwd_kernel_name": (c_char_p, [c_int] * 6),
     "fa_dtype_in_bytes": (c_int, [c_int]),
     "fa_dtype_out_bytes": (c_int, [c_int]),
     "fa_algorithmic_flops": (c_double, [c_int, c_int, c_int, c_int, c_int]),

@@ -7,6 +7,10 @@
 
 #include "fa_common.h"
 
+#ifndef FA_PP_MIN_BLOCKS
+#define FA_PP_MIN_BLOCKS 1000000000  // provisional: AUTO keeps the 128-row kernel until the paired-block kernel is measured
+#endif
+
 namespace {
 thread_local char g_err[512] = "";
 
@@ -31,6 +35,7 @@ const char *fa_variant_name(int v) {
     case FA_VARIANT_TILED: return "tiled";
     case FA_VARIANT_TILED_V2: return "tiled_v2";
     case FA_VARIANT_MFMA: return "mfma";
+    case FA_VARIANT_MFMA_PP: return "mfma_pp";
     default: return "?";
   }
 }
@@ -60,6 +65,7 @@ int fa_supported(int dtype, int variant, int D) {
     case FA_VARIANT_TILED: return fa::tiled_supported(dtype, D);
     case FA_VARIANT_TILED_V2: return fa::tiled_v2_supported(dtype, D);
     case FA_VARIANT_MFMA: return fa::mfma_supported(dtype, D);
+    case FA_VARIANT_MFMA_PP: return fa::pp_supported(dtype, D);
     default: return 0;
   }
 }
@@ -67,6 +73,31 @@ int fa_resolve_variant(int dtype, int D) {
   if (fa::mfma_supported(dtype, D)) return FA_VARIANT_MFMA;
   if (fa::tiled_v2_supported(dtype, D)) return FA_VARIANT_TILED_V2;
   return FA_ERR_UNSUPPORTED;
+}
+
+// The paired-block kernel needs enough 256-row blocks to fill the chip; below that the 128-row kernel's
+// finer grid wins.
+int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal) {
+  (void)is_causal;
+  const int v = fa_resolve_variant(dtype, D);
+  if (v != FA_VARIANT_MFMA) return v;
+  const long long blocks256 = (long long)B * H * ((N + 255) / 256);
+  if (fa::pp_supported(dtype, D) && blocks256 >= FA_PP_MIN_BLOCKS) return FA_VARIANT_MFMA_PP;
+  return FA_VARIANT_MFMA;
+}
+
+const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_causal) {
+  static thread_local char name[96];
+  const int v = fa_resolve_variant_for(dtype, D, B, H, N, is_causal);
+  const char *tag = dtype == FA_DTYPE_F32 ? "float" : dtype == FA_DTYPE_F16 ? "fa::F16" : dtype == FA_DTYPE_BF16 ? "fa::BF16" : "fa::FP8";
+  const char *c = is_causal ? "true" : "false";
+  switch (v) {
+    case FA_VARIANT_MFMA_PP: snprintf(name, sizeof(name), "fa::fwd_pp_kernel<%s, %d, %s>", tag, D, c); break;
+    case FA_VARIANT_MFMA: snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s>", tag, D, c); break;
+    case FA_VARIANT_TILED_V2: snprintf(name, sizeof(name), "fa::tiled_v2_kernel"); break;
+    default: name[0] = 0;
+  }
+  return name;
 }
 
 double fa_algorithmic_flops(int B, int H, int N, int D, int is_causal) {
@@ -99,7 +130,7 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
   if ((long long)B * H > 0x7fffffffLL / ((N + 127) / 128))
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: grid too large");
   if (variant == FA_VARIANT_AUTO) {
-    variant = fa_resolve_variant(dtype, D);
+    variant = fa_resolve_variant_for(dtype, D, B, H, N, is_causal);
     if (variant < 0)
       return fail(FA_ERR_UNSUPPORTED, "fa_fwd: no kernel for dtype=%s D=%d", fa_dtype_name(dtype), D);
   }
@@ -124,6 +155,7 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
     case FA_VARIANT_NAIVE: e = fa::launch_naive(p, dtype, s); break;
     case FA_VARIANT_TILED: e = fa::launch_tiled(p, dtype, s); break;
     case FA_VARIANT_TILED_V2: e = fa::launch_tiled_v2(p, dtype, s); break;
+    case FA_VARIANT_MFMA_PP: e = fa::launch_pp(p, dtype, s); break;
     default: e = fa::launch_mfma(p, dtype, s); break;
   }
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)
@@ -155,6 +187,8 @@ int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse, 
     return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: tensors must be 16-byte aligned");
   if ((double)std::max(Nq, Nk) * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)
     return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: one head exceeds 4 GiB");
+  if (q_batch_stride < 0 || kv_batch_stride < 0) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: negative batch stride");
+  if ((long long)B * Hq > 0x7fffffffLL / ((Nq + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: grid too large");
   fa::Params p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
   p.B = B; p.H = Hq; p.N = Nq; p.D = D; p.scale = scale;
@@ -187,6 +221,8 @@ int fa_bwd(const void *q, const void *k, const void *v, const void *o, const voi
   if (!fa::bwd_supported(dtype, D))
     return fail(FA_ERR_UNSUPPORTED, "fa_bwd: no kernel for dtype=%s D=%d (f16/bf16, D=64)", fa_dtype_name(dtype), D);
   if ((double)N * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "fa_bwd: one head exceeds 4 GiB");
+  if (batch_stride < 0) return fail(FA_ERR_INVALID_ARG, "fa_bwd: negative batch stride");
+  if ((long long)B * H > 0x7fffffffLL / ((N + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "fa_bwd: grid too large");
   hipError_t e = fa::launch_bwd(q, k, v, o, d_o, lse, dq, dk, dv, (float *)workspace, B, H, N, D, scale, batch_stride,
                                 head_stride, is_causal ? 1 : 0, dtype, (hipStream_t)hip_stream);
   if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_bwd: launch failed: %s", hipGetErrorString(e));

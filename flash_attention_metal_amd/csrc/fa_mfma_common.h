@@ -1,6 +1,9 @@
 // fa_mfma_common.h -- types and lane-level helpers shared by the matrix-core kernels.
 #pragma once
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 #include "fa_common.h"
 
@@ -15,12 +18,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <typename Tag> struct MT;
+// mfma_v0 / mfma_v: the same instruction through inline asm with the accumulator tuple forced into
+// ARCHITECTURAL VGPRs ("v"). In a kernel that may use the accumulation file (one wave per SIMD,
+// launch_bounds(256,1)) hipcc selects the AGPR form for every builtin MFMA; a score tile that the
+// softmax reads next would then cost one v_accvgpr_read per element. hipcc pads no hazards around an
+// asm statement: callers keep >= 12 wait states between the last mfma_v of a chain and the first VALU
+// read of its result (cdna_hip_programming.md section 5.7 item 2).
+#define FA_MFMA_ASM(OP)                                                                              \
+  __device__ static __forceinline__ void mfma_v0(f32x16 &d, u32x4 a, u32x4 b) {                          \
+    asm volatile(OP " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));                                  \
+  }                                                                                                  \
+  __device__ static __forceinline__ void mfma_v(f32x16 &d, u32x4 a, u32x4 b) {                           \
+    asm volatile(OP " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));                                  \
+  }
+
 template <> struct MT<BF16> {
   using elem = __bf16;
   using vec8 = bf16x8;
   __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  FA_MFMA_ASM("v_mfma_f32_32x32x16_bf16")
 };
 template <> struct MT<F16> {
   using elem = _Float16;
@@ -28,6 +46,7 @@ template <> struct MT<F16> {
   __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
+  FA_MFMA_ASM("v_mfma_f32_32x32x16_f16")
 };
 
 template <> struct MT<FP8> {  // e4m3 inputs: converted to bf16 on the way into registers / LDS (exact),
@@ -36,7 +55,62 @@ template <> struct MT<FP8> {  // e4m3 inputs: converted to bf16 on the way into 
   __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
   }
+  FA_MFMA_ASM("v_mfma_f32_32x32x16_bf16")
 };
+
+
+// ---- asm-owned accumulation registers -------------------------------------------------------------
+// The paired-block kernel keeps O^T in FIXED accumulation registers a[0 : NACC) that only the inline
+// asm below names: hipcc neither allocates nor copies them. (Left to the register allocator, 16-wide
+// accumulator tuples that live across the loop's rare branches were copied on the COMMON path: 32
+// v_accvgpr_mov per 32x64 score tile.) Every statement lists the whole range as clobbered, which also
+// makes the kernel descriptor reserve it. hipcc pads no hazards around asm: see the callers' s_nop.
+#define FA_A64 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
+#define FA_A128 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// a[16*TI .. 16*TI+15] += A(frag) * B(frag)   (32x32x16, A/B in VGPRs)
+template <typename Tag, int NACC, int TI>
+__device__ __forceinline__ void acc_mfma(u32x4 a, u32x4 b) {
+  constexpr int lo = 16 * TI, hi = lo + 15;
+  static_assert(hi < NACC, "accumulator tuple out of range");
+#define FA_ACC_MFMA(OP, CL) asm volatile(OP " a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(lo), "i"(hi) : CL)
+  if constexpr (std::is_same<Tag, F16>::value) {
+    if constexpr (NACC == 64) FA_ACC_MFMA("v_mfma_f32_32x32x16_f16", FA_A64);
+    else FA_ACC_MFMA("v_mfma_f32_32x32x16_f16", FA_A128);
+  } else {
+    if constexpr (NACC == 64) FA_ACC_MFMA("v_mfma_f32_32x32x16_bf16", FA_A64);
+    else FA_ACC_MFMA("v_mfma_f32_32x32x16_bf16", FA_A128);
+  }
+#undef FA_ACC_MFMA
+}
+template <int NACC, int R>
+__device__ __forceinline__ void acc_zero1() {
+  if constexpr (NACC == 64) asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"i"(R) : FA_A64);
+  else asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"i"(R) : FA_A128);
+}
+template <int NACC, int R>
+__device__ __forceinline__ float acc_read1() {
+  float f;
+  if constexpr (NACC == 64) asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(f) : "i"(R) : FA_A64);
+  else asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(f) : "i"(R) : FA_A128);
+  return f;
+}
+template <int NACC, int R>
+__device__ __forceinline__ void acc_scale1(float alpha) {  // a[R] *= alpha (per lane)
+  float t;
+#define FA_ACC_SCALE(CL) asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c2, %0" : "=&v"(t) : "v"(alpha), "i"(R) : CL)
+  if constexpr (NACC == 64) FA_ACC_SCALE(FA_A64);
+  else FA_ACC_SCALE(FA_A128);
+#undef FA_ACC_SCALE
+}
 
 constexpr int BM = 128;      // query rows per workgroup
 constexpr int WM = 32;       // query rows per wave
@@ -129,6 +203,38 @@ __device__ __forceinline__ void map_block(int id, int BH, int nQ, int &bh, int &
     bh = full + rem / nQ;
     qb = rem % nQ;
   }
+}
+
+// ---- host-side launch helpers shared by the matrix-core kernel files ---------------------------
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch.
+inline hipError_t set_dyn_lds_once(const void *fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void *, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({fn, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert({fn, dev});
+  return e;
+}
+
+// Causal issue order: heaviest-first within groups of `head_group` heads (map_block above).
+// One global group balances best. Measured on config 3 (1 MiB of K+V per head, 8 heads per XCD
+// in flight): 279 MB fetched per launch vs 140 MB with 32-head groups (algorithmic reads 101 MB),
+// but the global order is 3.6 % FASTER (interleaved A/B) -- the re-reads are served by the
+// 256 MiB Infinity Cache, not HBM. Groups are therefore only used where they cost nothing:
+// long sequences, sized so that one XCD's share of K+V stays under 8 MiB (floor: 16 heads).
+inline int causal_head_group(const Params &p, int D, int elem_bytes) {
+  const int BH = p.B * p.H;
+  const double kv_bytes = 2.0 * p.Nk * D * elem_bytes;
+  int per_xcd = (int)(8.0 * 1024 * 1024 / kv_bytes);
+  if (per_xcd < 2) per_xcd = 2;
+  int hg = 8 * per_xcd;
+  while (hg < BH && (BH % hg) != 0) hg += 8;
+  return (BH % 8 == 0 && hg < BH) ? hg : 0;
 }
 
 }  // namespace fa

@@ -30,6 +30,9 @@
 
 #include "fa_mfma_common.h"
 
+#ifndef FA_DEFER_THR
+#define FA_DEFER_THR 8.0f  // log2 units: P values are bounded by 2^8 between rescales (0 = rescale whenever a max moved)
+#endif
 #ifndef FA_PRIO
 #define FA_PRIO 2  // wave priority: 2 = raised around the MFMA clusters (+0.4..0.9 % A/B), 1 = around the softmax (-1..-6 %), 0 = off
 #endif
@@ -169,9 +172,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[db][i] = 0.0f;
-  float m = -INFINITY;  // running max of the raw (unscaled) scores of this row
-  float l = 0.0f;       // this lane half's share of the running sum
+  float m = -INFINITY;     // reference max of the raw (unscaled) scores of this row (may lag the true max by < 2^THR)
+  float mthr = -INFINITY;  // m + threshold: a tile max above it forces a rescale
+  float l = 0.0f;          // this lane half's share of the running sum
   const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
+  const float thr_raw = FA_DEFER_THR / c2;         // the threshold in raw-score units
 
   stage_load(0);
   stage_write(0);
@@ -280,8 +285,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
         half_pair(mx, lo, hi);
         mx = fmaxf(lo, hi);
       }
-      const float m_new = fmaxf(m, mx);
-      if (__builtin_amdgcn_ballot_w64(m_new > m) != 0) {  // wave-uniform; exact skip when no max moved
+      // deferred row max (T13): O and l are rescaled only when some row's tile max exceeds the running
+      // reference m by more than 2^THR (log2 domain); otherwise p = exp2(c.s - c.m) <= 2^THR with the
+      // stale m. m, l and O stay mutually consistent, so LSE = m.scale + ln(l) is exact either way.
+      // On random data a 32-row wave sees SOME row's max move in most tiles, so the exact form
+      // (rescale whenever a max moved) paid the 32-multiply O pass nearly every tile.
+      if (__builtin_amdgcn_ballot_w64(mx > mthr) != 0) {  // wave-uniform; first tile: mthr = -inf
+        const float m_new = fmaxf(m, mx);
         const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c2);
         l *= alpha;
 #pragma unroll
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
         m = m_new;
+        mthr = m_new + thr_raw;
       }
       const float mc = m * c2;
       float ls0 = 0.0f, ls1 = 0.0f;
@@ -407,27 +418,16 @@ static hipError_t launch_one(const Params &p, hipStream_t s) {
   const size_t smem = 4 * BN * D * 2;
   auto kern = fwd_mfma_kernel<Tag, D, CAUSAL>;
   if (smem > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
     if (e != hipSuccess) return e;
   }
   Params pp = p;
-  // Causal issue order: heaviest-first within groups of `head_group` heads (fa_mfma_common.h).
-  // One global group balances best. Measured on config 3 (1 MiB of K+V per head, 8 heads per XCD
-  // in flight): 279 MB fetched per launch vs 140 MB with 32-head groups (algorithmic reads 101 MB),
-  // but the global order is 3.6 % FASTER (interleaved A/B) -- the re-reads are served by the
-  // 256 MiB Infinity Cache, not HBM. Groups are therefore only used where they cost nothing:
-  // long sequences, sized so that one XCD's share of K+V stays under 8 MiB (floor: 16 heads).
-  {
-    const int BH = p.B * p.H;
-    const double kv_bytes = 2.0 * p.Nk * D * (std::is_same<Tag, FP8>::value ? 1 : 2);
-    int per_xcd = (int)(8.0 * 1024 * 1024 / kv_bytes);
-    if (per_xcd < 2) per_xcd = 2;
-    int hg = 8 * per_xcd;
-    while (hg < BH && (BH % hg) != 0) hg += 8;
-    pp.head_group = (BH % 8 == 0 && hg < BH) ? hg : 0;
-  }
+  pp.head_group = causal_head_group(p, D, std::is_same<Tag, FP8>::value ? 1 : 2);
+#ifdef FA_DEBUG_KNOBS  // scheduling experiments only: never compiled into the shipped library
   static const int env_head_group = [] { const char *e = getenv("FA_HEAD_GROUP"); return e ? atoi(e) : -1; }();
-  if (env_head_group >= 0) pp.head_group = env_head_group;  // scheduling experiments only (read once)
+  if (env_head_group >= 0) pp.head_group = env_head_group;
+#endif
+  (void)hipGetLastError();  // do not report an older sticky error as this launch's
   hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
   return hipGetLastError();
 }
@@ -438,14 +438,7 @@ static hipError_t launch_dt(const Params &p, hipStream_t s) {
   return p.is_causal ? launch_one<Tag, 128, true>(p, s) : launch_one<Tag, 128, false>(p, s);
 }
 
-hipError_t launch_mfma_pipe_d64(const Params &p, int dtype, hipStream_t s);  // fa_mfma_pipe_kernel.hip
-
 hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s) {
-  // experimental software-pipelined head_dim-64 kernel: opt-in, square multi-head problems only
-  static const bool env_pipe = getenv("FA_MFMA_PIPE") != nullptr;
-  if (env_pipe && p.D == 64 && dtype != FA_DTYPE_FP8_E4M3 && p.Nk == p.N && p.Hkv == p.H &&
-      p.kv_batch_stride == p.batch_stride && p.kv_head_stride == p.head_stride)
-    return launch_mfma_pipe_d64(p, dtype, s);  // experimental software-pipelined kernel
   if (dtype == FA_DTYPE_FP8_E4M3) return launch_dt<FP8>(p, s);
   return dtype == FA_DTYPE_F16 ? launch_dt<F16>(p, s) : launch_dt<BF16>(p, s);
 }

@@ -17,7 +17,7 @@ import torch
 from ._lib import load_library
 
 DTYPES = {"f32": 0, "f16": 1, "bf16": 2, "fp8_e4m3": 3}
-VARIANTS = {"auto": 0, "naive": 1, "tiled": 2, "tiled_v2": 3, "mfma": 4}
+VARIANTS = {"auto": 0, "naive": 1, "tiled": 2, "tiled_v2": 3, "mfma": 4, "mfma_pp": 5}
 
 _TORCH2FA = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 if hasattr(torch, "float8_e4m3fn"):
@@ -40,6 +40,11 @@ def algorithmic_flops(B: int, H: int, N: int, D: int, is_causal: bool) -> float:
 
 def algorithmic_bytes(B: int, H: int, N: int, D: int, dtype: str) -> float:
     return float(load_library().fa_algorithmic_bytes(B, H, N, D, DTYPES[dtype]))
+
+
+def forward_kernel_name(dtype: str, D: int, is_causal: bool, B: int = 4, H: int = 16, N: int = 4096) -> str:
+    """Name (as rocprofv3 prints it) of the device kernel variant "auto" launches for the problem."""
+    return load_library().fa_fwd_kernel_name(DTYPES[dtype], D, B, H, N, int(is_causal)).decode()
 
 
 def _strides(t: torch.Tensor) -> Tuple[int, int]:

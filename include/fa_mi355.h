@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FA_MI355_VERSION 100 /* major*10000 + minor*100 + patch */
+#define FA_MI355_VERSION 200 /* major*10000 + minor*100 + patch */
 
 /* element type of Q, K, V and O */
 enum fa_dtype {
@@ -53,7 +53,9 @@ enum fa_variant {
   FA_VARIANT_NAIVE = 1,  /* one thread per query row, two passes   (kernels.metal:12-64)   */
   FA_VARIANT_TILED = 2,  /* LDS-tiled scalar "V1"                  (kernels.metal:72-171)  */
   FA_VARIANT_TILED_V2 = 3, /* 128-bit loads, double-buffered K/V "V2" (kernels.metal:462-596) */
-  FA_VARIANT_MFMA = 4    /* matrix-core kernel "V3/V4"             (kernels.metal:177,600) */
+  FA_VARIANT_MFMA = 4,   /* matrix-core kernel "V3/V4"             (kernels.metal:177,600): 128 query rows per workgroup */
+  FA_VARIANT_MFMA_PP = 5 /* same operator, paired-block pipeline: 256 query rows per workgroup, each wave interleaves the
+                            softmax of one 32-row block with the matrix products of the other (large grids) */
 };
 
 /* status codes (0 = success, negative = error; text via fa_last_error()) */
@@ -131,6 +133,14 @@ int fa_supported(int dtype, int variant, int D);
 
 /* variant FA_VARIANT_AUTO resolves to for (dtype, D); FA_ERR_UNSUPPORTED if none. */
 int fa_resolve_variant(int dtype, int D);
+
+/* variant FA_VARIANT_AUTO resolves to for a whole problem (the choice between the matrix-core kernels depends on
+ * the grid the shape gives); FA_ERR_UNSUPPORTED if none. */
+int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal);
+
+/* name of the device kernel fa_fwd(..., FA_VARIANT_AUTO) launches for the problem, as rocprofv3 prints it
+ * (e.g. "fa::fwd_pp_kernel<fa::BF16, 64, true>"); "" if none. Static storage. */
+const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_causal);
 
 /* bytes per element of Q/K/V and of O for a dtype (fp8: 1 and 2). 0 if bad enum. */
 int fa_dtype_in_bytes(int dtype);

@@ -19,6 +19,13 @@ pytestmark = pytest.mark.gpu
 
 TOL_O = {"f32": 2e-5, "f16": 1.5e-3, "bf16": 6e-3}
 TOL_LSE = {"f32": 2e-5, "f16": 1e-4, "bf16": 1e-4}
+# the matrix-core kernels: 128-row workgroups ("mfma"), paired-block pipeline ("mfma_pp"); "auto" picks by grid size
+MFMA_VARIANTS = ["mfma", "mfma_pp"]
+
+
+def need(fa, dtype, variant, D):
+    if not fa.supported({"fp8": "fp8_e4m3"}.get(dtype, dtype), variant, D):
+        pytest.skip(f"{variant} has no kernel for {dtype} D={D}")
 
 
 @pytest.fixture(scope="module")
@@ -83,59 +90,66 @@ def test_scalar_variants_batched_ragged(fa, oracle_mod, variant, dtype):
 # --------------------------------------------------------------------------
 # the matrix-core operator
 # --------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("causal", [False, True])
-def test_mfma_vs_oracle(fa, oracle_mod, dtype, D, causal):
+def test_mfma_vs_oracle(fa, oracle_mod, dtype, D, causal, variant):
+    need(fa, dtype, variant, D)
     # N: multiples of the tile, ragged, < one tile, > several q blocks
     for (B, H, N) in ((1, 1, 128), (2, 3, 200), (1, 2, 1), (1, 1, 63), (1, 2, 65), (1, 1, 129), (2, 2, 1000),
-                      (1, 8, 1024)):
+                      (1, 8, 1024), (1, 2, 255), (1, 1, 257), (1, 3, 576)):
         q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype)
-        check(fa, oracle_mod, q, k, v, dtype, causal, "mfma")
+        check(fa, oracle_mod, q, k, v, dtype, causal, variant)
 
 
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
 @pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("causal", [False, True])
-def test_mfma_fp8_inputs_vs_oracle(fa, oracle_mod, D, causal):
+def test_mfma_fp8_inputs_vs_oracle(fa, oracle_mod, D, causal, variant):
+    need(fa, "fp8", variant, D)
     # BASELINE config 5 family: Q,K,V OCP e4m3fn (saturating RNE), fp32 accumulate, bf16 O.
     # The oracle sees exactly the e4m3 values, so only P/O rounding (bf16) separates the two.
     for (B, H, N) in ((1, 1, 128), (2, 3, 200), (1, 2, 65), (2, 2, 1000)):
         for amp in (1.0, 3.0):  # amp 3: values up to 3 exercise more of the e4m3 grid
             q, k, v = make_qkv(oracle_mod, B, H, N, D, "fp8", amp=amp)
-            o, lse = run_op(fa, q, k, v, "fp8", causal, "mfma")
+            o, lse = run_op(fa, q, k, v, "fp8", causal, variant)
             o64, l64 = oracle_mod.attn_fwd_f64(q, k, v, causal)
             assert np.abs(o - o64).max() < TOL_O["bf16"] * amp, (B, H, N, D, causal, amp)
             assert np.abs(lse - l64).max() < 1e-4 * amp * amp
 
 
-def test_fp8_equals_bf16_kernel_on_same_values(fa, oracle_mod):
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
+def test_fp8_equals_bf16_kernel_on_same_values(fa, oracle_mod, variant):
     # e4m3 -> bf16 is exact, so the fp8-input kernel must reproduce the bf16 kernel bit for bit
     import torch
 
     q, k, v = make_qkv(oracle_mod, 2, 4, 320, 64, "fp8", amp=2.0)
     for causal in (False, True):
-        o8, l8 = run_op(fa, q, k, v, "fp8", causal, "mfma")
-        ob, lb = run_op(fa, q, k, v, "bf16", causal, "mfma")
+        o8, l8 = run_op(fa, q, k, v, "fp8", causal, variant)
+        ob, lb = run_op(fa, q, k, v, "bf16", causal, variant)
         assert np.array_equal(o8, ob) and np.array_equal(l8, lb)
 
 
-def test_mfma_reference_mode_same_qkv_n1024(fa, oracle_mod):
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
+def test_mfma_reference_mode_same_qkv_n1024(fa, oracle_mod, variant):
     # main.mm:381-456 (V4 vs naive, N=1024, Q=K=V, fp16, tol 1e-2) and :458-594 (causal N=128)
     x = oracle_mod.round_to(oracle_mod.init_random(1024 * 64, 42).reshape(1, 1, 1024, 64), "f16")
-    check(fa, oracle_mod, x, x, x, "f16", False, "mfma")
+    check(fa, oracle_mod, x, x, x, "f16", False, variant)
     xc = x[:, :, :128].copy()
-    check(fa, oracle_mod, xc, xc, xc, "f16", True, "mfma")
+    check(fa, oracle_mod, xc, xc, xc, "f16", True, variant)
 
 
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_causal_row0_is_v0_bit_exact(fa, oracle_mod, dtype):
+def test_causal_row0_is_v0_bit_exact(fa, oracle_mod, dtype, variant):
     q, k, v = make_qkv(oracle_mod, 2, 2, 300, 64, dtype)
-    o, lse = run_op(fa, q, k, v, dtype, True, "mfma")
+    o, lse = run_op(fa, q, k, v, dtype, True, variant)
     assert np.array_equal(o[:, :, 0], v[:, :, 0])  # softmax over one key: O[0] == V[0]
 
 
-@pytest.mark.parametrize("variant,dtype", [("mfma", "bf16"), ("mfma", "f16"), ("tiled_v2", "f32"), ("tiled", "f32"),
-                                           ("naive", "f32")])
+@pytest.mark.parametrize("variant,dtype", [("mfma", "bf16"), ("mfma", "f16"), ("mfma_pp", "bf16"), ("mfma_pp", "f16"),
+                                           ("tiled_v2", "f32"), ("tiled", "f32"), ("naive", "f32")])
 def test_mask_index_probe_exact(fa, oracle_mod, variant, dtype):
     # Q = 0 -> uniform softmax; V[j,0] = delta(j,t): causal O[i,0] = 1/(i+1) for i >= t, EXACTLY 0 left of it.
     # t straddles every tile / wave / block boundary of the kernels (32, 64, 128).
@@ -159,8 +173,9 @@ def test_mask_index_probe_exact(fa, oracle_mod, variant, dtype):
         assert np.all(np.abs(o[0, 0, :, 0] - oracle_mod.round_to(np.float32(1.0 / N), dtype)) <= ulp / N)
 
 
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_forced_rescale_branch(fa, oracle_mod, dtype):
+def test_forced_rescale_branch(fa, oracle_mod, dtype, variant):
     # cdna guide rule 26: force the running max to jump at chosen tiles. Key j* is a spiked copy of
     # query i*, so row i* meets a much larger score at tile j*/64 (and the wave takes its rescale path).
     B, H, N, D = 1, 2, 512, 64
@@ -168,38 +183,53 @@ def test_forced_rescale_branch(fa, oracle_mod, dtype):
     for (istar, jstar) in ((5, 130), (300, 3), (300, 290), (511, 448), (64, 64), (200, 199)):
         k[:, :, jstar] = oracle_mod.round_to(q[:, :, istar] * 6.0, dtype)
     for causal in (False, True):
-        check(fa, oracle_mod, q, k, v, dtype, causal, "mfma")
+        check(fa, oracle_mod, q, k, v, dtype, causal, variant)
     # large-magnitude scores: exercises exp2 range and max tracking (scale folded in log2 domain)
     q2, k2, v2 = make_qkv(oracle_mod, 1, 1, 256, 64, dtype, amp=4.0)
-    check(fa, oracle_mod, q2, k2, v2, dtype, True, "mfma", tol_scale=4.0)
+    check(fa, oracle_mod, q2, k2, v2, dtype, True, variant, tol_scale=4.0)
+    # deferred-max kernels (mfma_pp): the row max creeps up tile after tile by less than the rescale
+    # threshold (2^8), then jumps far above it: exercises both the deferred and the taken path, on every
+    # row of one block and on a single row of another
+    N2 = 1024
+    q3, k3, v3 = make_qkv(oracle_mod, 1, 2, N2, D, dtype, seeds=(7, 8, 9))
+    ramp = (np.arange(N2, dtype=np.float32) / N2)[None, None, :, None]  # keys grow towards the end
+    k3 = oracle_mod.round_to(k3 * 0.25 + q3[:, :, 100:101] * ramp * 3.0, dtype)   # scores of row 100 ramp up smoothly
+    k3[:, :, 900] = oracle_mod.round_to(q3[:, :, 100] * 8.0, dtype)              # ... and jump at key 900
+    for causal in (False, True):
+        check(fa, oracle_mod, q3, k3, v3, dtype, causal, variant, tol_scale=2.0)
 
 
-def test_asymmetric_structure(fa, oracle_mod):
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
+def test_asymmetric_structure(fa, oracle_mod, variant):
     # catches K<->V swaps, transposed S, wrong-row V gathers that Q==K==V data cannot
     N, D = 256, 64
     q, k, _ = make_qkv(oracle_mod, 1, 1, N, D, "bf16")
     v = np.zeros((1, 1, N, D), np.float32)
     v[0, 0] = oracle_mod.round_to((np.arange(N)[:, None] % 7 - 3) * 0.25 + (np.arange(D)[None, :] % 5) * 0.125, "bf16")
     for causal in (False, True):
-        check(fa, oracle_mod, q, k, v, "bf16", causal, "mfma")
+        check(fa, oracle_mod, q, k, v, "bf16", causal, variant)
 
 
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_head_batch_addressing_bit_exact(fa, oracle_mod, dtype):
+def test_head_batch_addressing_bit_exact(fa, oracle_mod, dtype, variant):
+    import functools
+
     import torch
 
-    B, H, N, D = 3, 5, 192, 64
+    B, H, N, D = 3, 5, 320, 64
     q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype)
     qd, kd, vd = (to_dev(x, dtype) for x in (q, k, v))
-    o_all, l_all = fa.flash_attention_forward(qd, kd, vd, is_causal=True)
+    fwd = functools.partial(fa.flash_attention_forward, variant=variant)
+    o_all, l_all = fwd(qd, kd, vd, is_causal=True)
     # (1) each (b,h) slice alone gives the same bits as inside the batch
     for b, h in ((0, 0), (1, 3), (2, 4)):
-        o1, l1 = fa.flash_attention_forward(qd[b:b + 1, h:h + 1].contiguous(), kd[b:b + 1, h:h + 1].contiguous(),
+        o1, l1 = fwd(qd[b:b + 1, h:h + 1].contiguous(), kd[b:b + 1, h:h + 1].contiguous(),
                                             vd[b:b + 1, h:h + 1].contiguous(), is_causal=True)
         assert torch.equal(o1[0, 0], o_all[b, h]) and torch.equal(l1[0, 0], l_all[b, h])
     # (2) permuting heads permutes outputs
     perm = torch.tensor([3, 0, 4, 1, 2], device="cuda")
-    o_p, l_p = fa.flash_attention_forward(qd[:, perm].contiguous(), kd[:, perm].contiguous(), vd[:, perm].contiguous(),
+    o_p, l_p = fwd(qd[:, perm].contiguous(), kd[:, perm].contiguous(), vd[:, perm].contiguous(),
                                           is_causal=True)
     assert torch.equal(o_p, o_all[:, perm]) and torch.equal(l_p, l_all[:, perm])
     # (3) padded batch/head strides (binding table slots 7,8: kernels.metal:608-609)
@@ -210,12 +240,13 @@ def test_head_batch_addressing_bit_exact(fa, oracle_mod, dtype):
         return view
     qp, kp, vp = padded(qd), padded(kd), padded(vd)
     assert qp.stride() == ((H + 1) * (N + 8) * D, (N + 8) * D, D, 1)
-    o_s, l_s = fa.flash_attention_forward(qp, kp, vp, is_causal=True)
+    o_s, l_s = fwd(qp, kp, vp, is_causal=True)
     assert torch.equal(o_s, o_all) and torch.equal(l_s, l_all)
     torch.cuda.synchronize()
 
 
-def test_randomized_shapes(fa, oracle_mod):
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
+def test_randomized_shapes(fa, oracle_mod, variant):
     # seeded random (B, H, N, D, dtype, causal, scale): ragged N everywhere, both head dims, custom scales
     rng = np.random.default_rng(2024)
     for _ in range(40):
@@ -225,8 +256,11 @@ def test_randomized_shapes(fa, oracle_mod):
         dtype = str(rng.choice(["f16", "bf16", "fp8"]))
         causal = bool(rng.integers(0, 2))
         scale = float(rng.choice([D ** -0.5, 0.05, 0.2]))
-        q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype, seeds=tuple(int(x) for x in rng.integers(1, 10 ** 6, 3)))
-        o, lse = run_op(fa, q, k, v, dtype, causal, "mfma", scale)
+        seeds = tuple(int(x) for x in rng.integers(1, 10 ** 6, 3))
+        if not fa.supported({"fp8": "fp8_e4m3"}.get(dtype, dtype), variant, D):
+            continue
+        q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype, seeds=seeds)
+        o, lse = run_op(fa, q, k, v, dtype, causal, variant, scale)
         o64, l64 = oracle_mod.attn_fwd_f64(q, k, v, causal, scale)
         tol = TOL_O["f16"] if dtype == "f16" else TOL_O["bf16"]
         assert np.abs(o - o64).max() < tol, (B, H, N, D, dtype, causal, scale)
@@ -379,14 +413,18 @@ def test_error_behaviour_on_device(fa):
 # BASELINE.json configurations at FULL size: sampled rows vs the fp64 oracle +
 # size-independent properties
 # --------------------------------------------------------------------------
-def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48):
+def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, variant="auto"):
+    import functools
+
     import torch
+
+    fwd = functools.partial(fa.flash_attention_forward, variant=variant)
 
     g = torch.Generator(device="cuda").manual_seed(1234)
     tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
     q, k, v = (torch.rand(B, H, N, D, generator=g, device="cuda", dtype=torch.float32).mul_(2).sub_(1).to(tdt)
                for _ in range(3))
-    o, lse = fa.flash_attention_forward(q, k, v, is_causal=causal)
+    o, lse = fwd(q, k, v, is_causal=causal)
     torch.cuda.synchronize()
     assert torch.isfinite(o).all() and torch.isfinite(lse).all()
     if causal:  # row 0 attends to key 0 only
@@ -405,20 +443,24 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48):
     assert worst_o < TOL_O[dtype] and worst_l < TOL_LSE[dtype], (worst_o, worst_l)
     # V = const -> O = const (the softmax weights sum to 1), any size
     ones = torch.full_like(v, 0.5)
-    o1, _ = fa.flash_attention_forward(q, k, ones, is_causal=causal)
+    o1, _ = fwd(q, k, ones, is_causal=causal)
     assert (o1.float() - 0.5).abs().max().item() <= 0.5 * 2 ** -7
     # rerun is deterministic bit for bit
-    o2, lse2 = fa.flash_attention_forward(q, k, v, is_causal=causal)
+    o2, lse2 = fwd(q, k, v, is_causal=causal)
     assert torch.equal(o, o2) and torch.equal(lse, lse2)
     torch.cuda.synchronize()
 
 
-def test_config2_full(fa, oracle_mod):  # seqlen=1024, D=64, B=1, H=8, fp16, non-causal
-    _full_size(fa, oracle_mod, 1, 8, 1024, 64, "f16", False, [(0, 0), (0, 7)])
+@pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_pp"])
+def test_config2_full(fa, oracle_mod, variant):  # seqlen=1024, D=64, B=1, H=8, fp16, non-causal
+    # BASELINE configs[1] names the "V2-style tiled kernel": variant tiled_v2 (kernels.metal:462-596) runs it at
+    # full size in fp16; the matrix-core kernels are checked on the same tensors
+    _full_size(fa, oracle_mod, 1, 8, 1024, 64, "f16", False, [(0, 0), (0, 7)], variant=variant)
 
 
-def test_config3_full(fa, oracle_mod):  # seqlen=4096, D=64, B=4, H=16, bf16, causal
-    _full_size(fa, oracle_mod, 4, 16, 4096, 64, "bf16", True, [(0, 0), (1, 5), (3, 15)])
+@pytest.mark.parametrize("variant", ["auto", "mfma", "mfma_pp"])
+def test_config3_full(fa, oracle_mod, variant):  # seqlen=4096, D=64, B=4, H=16, bf16, causal
+    _full_size(fa, oracle_mod, 4, 16, 4096, 64, "bf16", True, [(0, 0), (1, 5), (3, 15)], variant=variant)
 
 
 def test_config5_full_fp8(fa, oracle_mod):  # seqlen=8192, D=64, fp8 in / fp32 acc, causal (B=4,H=16 assumed)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of several builds of libfa_mi355.so in ONE process (cdna guide rule 24).
-usage: ab.py libA.so libB.so [...] [--shapes c3,nc8k,c16k] [--rounds 8] [--iters 20]"""
+usage: ab.py libA.so[:variant] libB.so[:variant] [...] [--shapes c3,nc8k,c16k] [--rounds 8] [--iters 20]
+`lib.so:5` times variant 5 (mfma_pp) of that build; without a suffix --variant applies (0 = auto)."""
 import argparse, ctypes, os, sys
 from ctypes import c_int, c_float, c_longlong, c_void_p
 import torch
@@ -15,7 +16,10 @@ ap.add_argument("--rounds", type=int, default=8); ap.add_argument("--iters", typ
 ap.add_argument("--variant", type=int, default=0)
 a = ap.parse_args()
 libs = []
+variants = []
 for p in a.libs:
+    p, _, vs = p.partition(":")
+    variants.append(int(vs) if vs else a.variant)
     l = ctypes.CDLL(os.path.abspath(p))
     l.fa_fwd.restype = c_int
     l.fa_fwd.argtypes = [c_void_p] * 5 + [c_int] * 4 + [c_float, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p]
@@ -29,7 +33,7 @@ for name in a.shapes.split(","):
     st = torch.cuda.current_stream().cuda_stream
     def launch(l):
         rc = l.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, H, N, D, D ** -0.5,
-                      H * N * D, N * D, causal, fdt, a.variant, st)
+                      H * N * D, N * D, causal, fdt, variants[libs.index(l)], st)
         assert rc == 0, rc
     outs = []
     for l in libs:
@@ -48,5 +52,5 @@ for name in a.shapes.split(","):
     for i, p in enumerate(a.libs):
         ms = sorted(res[i]); med = ms[len(ms) // 2]
         same = "" if i == 0 else (" same-bits" if torch.equal(outs[i], outs[0]) else f" maxdiff={(outs[i].float()-outs[0].float()).abs().max().item():.2e}")
-        line += f" | {os.path.basename(p)}: med {med*1e3:8.1f}us {fl/med/1e9:7.1f}TF best {fl/ms[0]/1e9:7.1f}TF{same}"
+        line += f" | {os.path.basename(p.partition(':')[0])}:v{variants[i]}: med {med*1e3:8.1f}us {fl/med/1e9:7.1f}TF best {fl/ms[0]/1e9:7.1f}TF{same}"
     print(line, flush=True)
