@@ -1,0 +1,616 @@
+// fa_fwd_pp_kernel.hip -- the operator on the CDNA4 matrix cores, paired-block two-phase form.
+//
+// Same math and the same operand maps as fa_mfma_kernel.hip (replaces
+// /root/reference/kernels.metal:600-883): tiled QK^T -> online softmax -> PV, causal predicate
+// `key > query -> masked` (kernels.metal:748), whole-tile skip (kernels.metal:682),
+// L = m + ln(l) (kernels.metal:862-864); fp32 accumulators for S, O, m, l.
+//
+// One wave per SIMD with the whole register file; a wave owns TWO 32-row query blocks (A, B) that
+// move through the pipeline TOGETHER, so every K and every V^T fragment read from LDS feeds two
+// MFMAs, and the softmax of tile t+1 is cut in two halves that ride in the issue gaps of the matrix
+// phases on either side of it (score tiles double-buffered in VGPRs):
+//      phase Q(t):  MFMA  S(A,B; t+1) = K(t+1).Q^T        ||  VALU  finish softmax(t): exp2 (2nd half), row sums, pack P(t)
+//      phase P(t):  MFMA  O(A,B)     += V(t)^T.P(t)^T      ||  VALU  start softmax(t+1): row max, c.s - c.m, exp2 (1st half)
+// Why this shape (measured, profiles/r02): with one wave per SIMD every instruction of the stream
+// costs an issue slot, not only VALU: in the slot form of this kernel (one block per matrix phase,
+// tools/experiments) the LDS fragment reads and their s_waitcnt cost 20 % (head_dim 64) to 28 %
+// (head_dim 128) of the loop. Sharing fragments between the blocks halves them.
+//
+//   * workgroup = 4 waves = 256 query rows of one (batch, head); wave = 64 rows
+//   * asm-owned accumulation registers (fa_mfma_common.h): O^T of both blocks AND the Q fragments
+//     (B operand of the score product) live in a[0:NACC); S (2 buffers x 2 blocks) and P in VGPRs
+//   * K/V tiles of 64 keys double-buffered in LDS; one iteration consumes K(t+1) and V(t); loads of
+//     K(t+2), V(t+1) are issued at its start, written at its end: ONE barrier per 2 phases
+//   * deferred row max (T13): rescale only when a row's tile max exceeds the running reference by
+//     more than 2^THR. The decision for tile t+1 falls in the head of phase P(t); when it fires
+//     (rare) the phase finishes its MFMAs bare, O/l are rescaled AFTER the whole of P(t).V(t) is in
+//     O, and only then is tile t+1 exponentiated (against the new reference): nothing is ever
+//     scaled twice or not at all.
+//   * hot iterations carry no mask code; the wave's last one or two iterations run masked variants
+#include "fa_mfma_common.h"
+
+#ifndef FA_PP_TIOFF
+#define FA_PP_TIOFF 0
+#endif
+#ifndef FA_PP_THR
+#define FA_PP_THR 8.0f  // log2 units: P values are bounded by 2^8 between rescales
+#endif
+#ifndef FA_PP_LA
+#define FA_PP_LA 2      // LDS fragment reads are issued this many fragments (= 2 MFMAs each) ahead of their use
+#endif
+
+#ifdef FA_PP_DBGA0
+#define FA_DBG_POINT(n) do { if (FA_PP_DBGA0 == (n) && !dbg_done) { asm volatile("s_nop 15\n\ts_nop 7"); dbg_a0 = acc_read1<NACC, 16 * TIOFF + 0>(); dbg_a1 = acc_read1<NACC, 16 * TIOFF + 1>(); dbg_done = true; } } while (0)
+#else
+#define FA_DBG_POINT(n) do { } while (0)
+#endif
+
+namespace fa {
+
+constexpr int PP_BM = 256;  // query rows per workgroup
+constexpr int PP_WM = 64;   // query rows per wave (two 32-row blocks)
+
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
+  using M = MT<Tag>;
+  using elem = typename M::elem;
+  typedef elem elem2 __attribute__((ext_vector_type(2)));
+  constexpr int RB = D * 2;                 // LDS row bytes
+  constexpr int CPR = D / 8;                // 16-byte chunks per row
+  constexpr int KS = D / 16;                // k-steps of the QK^T product
+  constexpr int DB = D / 32;                // 32-wide d blocks of O^T
+#ifndef FA_PP_TIOFF
+#define FA_PP_TIOFF 0
+#endif
+  constexpr int TIOFF = FA_PP_TIOFF;        // debug: leave the first TIOFF accumulator tuples unused
+  constexpr int NACC_O = (2 * DB + TIOFF) * 16;  // O^T of block x, d block db = a[16(x DB + db) ..+15]
+  constexpr int NACC = (TIOFF ? 192 : NACC_O + 2 * KS * 4); // + Q fragment (x, ks) = a[NACC_O + 4(x KS + ks) ..+3]
+  constexpr int TILE = BN * RB;             // bytes of one K (or V) tile in LDS
+  constexpr bool IS_FP8 = std::is_same<Tag, FP8>::value;
+  constexpr int GB = IS_FP8 ? 1 : 2;
+  constexpr int GRB = D * GB;               // global row bytes
+  constexpr int GTILE = BN * GRB;
+  constexpr int GCPR = GRB / 16;
+  constexpr int NCH = BN * GCPR / NTHREADS; // staged 16-byte global chunks per thread per tile
+  constexpr int LA = FA_PP_LA;
+  constexpr int NU = 16;                    // per block and tile: 16 units of two scores each (unit u: kb = u/8, e = 2(u%8))
+  static_assert(NACC == 96 || NACC == 192, "head_dim 64 or 128");
+
+  extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+  lds_char *smem = (lds_char *)smem_generic;
+  lds_char *Kbuf = smem;             // [2][BN][RB], rows swizzled
+  lds_char *Vbuf = smem + 2 * TILE;  // [2][BN][RB], rows swizzled
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31;
+  const int h = lane >> 5;
+
+  const int nQ = (p.N + PP_BM - 1) / PP_BM;
+  const int BH = p.B * p.H;
+  int bh, qb;
+  map_block<CAUSAL>(blockIdx.x, BH, nQ, bh, qb, p.head_group);
+  const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
+  const long long base_kv = (long long)(bh / p.H) * p.kv_batch_stride + (long long)((bh % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
+  const int coff = p.Nk - p.N;  // bottom-right aligned causal mask for Nq != Nk
+  const int q0 = qb * PP_BM;
+  const int qw0 = q0 + wave * PP_WM;
+
+  const unsigned head_bytes = (unsigned)p.N * GRB, kv_head_bytes = (unsigned)p.Nk * GRB;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.q + base * GB), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.k + base_kv * GB), 0, kv_head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.v + base_kv * GB), 0, kv_head_bytes, 0x00020000);
+
+  // ---- per-lane LDS offsets (same images as fa_mfma_kernel.hip)
+  const int kx = (D == 64) ? ((r >> 1) & 7) : (r & 15);
+  int koff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) koff[ks] = r * RB + (((2 * ks + h) ^ kx) << 4);
+  const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
+  const int vx = (D == 64) ? (((vq >> 1) & 1) << 2) : (vq << 2);
+  int voff[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+    voff[db] = (4 * h + vq) * RB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
+
+  // ---- staging map: thread -> NCH 16-byte global chunks of a tile
+  int st_g[NCH], st_k[NCH], st_v[NCH], st_k1[IS_FP8 ? NCH : 1], st_v1[IS_FP8 ? NCH : 1];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NTHREADS;
+    const int row = c / GCPR, gch = c % GCPR;
+    st_g[i] = row * GRB + gch * 16;
+    const int skx = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    const int svx = (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+    const int ch = IS_FP8 ? 2 * gch : gch;
+    st_k[i] = row * RB + ((ch ^ skx) << 4);
+    st_v[i] = row * RB + ((ch ^ svx) << 4);
+    if constexpr (IS_FP8) {
+      st_k1[i] = row * RB + (((ch + 1) ^ skx) << 4);
+      st_v1[i] = row * RB + (((ch + 1) ^ svx) << 4);
+    }
+  }
+
+  // tiles: the workgroup stages nT tiles; this wave computes the first nTw of them. Iteration t is "hot"
+  // when tile t+1 exists for this wave and needs no mask for either block (tile t was masked, if at all,
+  // by the iteration before).
+  const int kv_end = CAUSAL ? min(p.Nk, q0 + PP_BM + coff) : p.Nk;
+  const int nT = (kv_end + BN - 1) / BN;
+  const int kv_end_w = CAUSAL ? min(p.Nk, qw0 + PP_WM + coff) : p.Nk;
+  const int nTw = (kv_end_w + BN - 1) / BN;  // >= 1 (causal needs Nk >= Nq, so key 0 is visible to every row)
+  int n_unmasked = p.Nk / BN;                // tile u is unmasked iff 64u+64 <= Nk and (causal) 64u+63 <= qw0+coff
+  if (CAUSAL) n_unmasked = min(n_unmasked, (qw0 + coff >= BN - 1) ? (qw0 + coff - (BN - 1)) / BN + 1 : 0);
+  const int nHot = min(nTw, n_unmasked) - 1;  // iterations t < nHot are hot (may be <= 0)
+
+  u32x4 kst[NCH], vst[NCH];
+  auto load_k = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)t * GTILE + st_g[i], 0, 0);
+  };
+  auto load_v = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)t * GTILE + st_g[i], 0, 0);
+  };
+  auto write_k = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if constexpr (IS_FP8) {
+        lds_write_b128(Kbuf + buf * TILE + st_k[i], fp8x8_to_bf16(u32x2{kst[i][0], kst[i][1]}));
+        lds_write_b128(Kbuf + buf * TILE + st_k1[i], fp8x8_to_bf16(u32x2{kst[i][2], kst[i][3]}));
+      } else {
+        lds_write_b128(Kbuf + buf * TILE + st_k[i], kst[i]);
+      }
+    }
+  };
+  auto write_v = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if constexpr (IS_FP8) {
+        lds_write_b128(Vbuf + buf * TILE + st_v[i], fp8x8_to_bf16(u32x2{vst[i][0], vst[i][1]}));
+        lds_write_b128(Vbuf + buf * TILE + st_v1[i], fp8x8_to_bf16(u32x2{vst[i][2], vst[i][3]}));
+      } else {
+        lds_write_b128(Vbuf + buf * TILE + st_v[i], vst[i]);
+      }
+    }
+  };
+
+  u32x4 qv[2][KS];  // (FA_PP_QVGPR builds only: Q fragments in VGPRs)
+  (void)qv;
+  // ---- prologue: Q fragments -> accumulation file; K(0), V(0), K(1) -> LDS; O = 0
+  static_for<0, NACC_O>([&](auto ic) __attribute__((always_inline)) { acc_zero1<NACC, decltype(ic)::value>(); });
+  {
+    // all loads in flight together; a tile past the end of the head reads as zero through the
+    // descriptor's range check and is never used
+    u32x4 k1[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) k1[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)GTILE + st_g[i], 0, 0);
+    load_k(0);
+    load_v(0);
+    // Q fragment (x, ks): lane (r,h) holds Q[qw0 + 32x + r][16ks + 8h .. +7] (B operand of K.Q^T); rows >= N read as zero
+    static_for<0, 2 * KS>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int x = decltype(ic)::value / KS, ks = decltype(ic)::value % KS;
+      const unsigned row = (unsigned)(qw0 + 32 * x + r);
+      u32x4 q;
+      if constexpr (IS_FP8) {
+        const u32x2 q8 = __builtin_amdgcn_raw_buffer_load_b64(rq, row * GRB + (2 * ks + h) * 8, 0, 0);
+        q = fp8x8_to_bf16(q8);
+      } else {
+        q = __builtin_amdgcn_raw_buffer_load_b128(rq, row * RB + (2 * ks + h) * 16, 0, 0);
+      }
+#ifdef FA_PP_QVGPR
+      qv[x][ks] = q;
+#else
+      constexpr int R0 = NACC_O + 4 * (x * KS + ks);
+      acc_write1<NACC, R0 + 0>(q[0]);
+      acc_write1<NACC, R0 + 1>(q[1]);
+      acc_write1<NACC, R0 + 2>(q[2]);
+      acc_write1<NACC, R0 + 3>(q[3]);
+#endif
+    });
+    write_k(0);
+    write_v(0);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) kst[i] = k1[i];
+    write_k(1);
+  }
+  __syncthreads();
+
+  // ---- per-block state (index 0 = A, 1 = B; every use below has a compile-time index)
+  f32x16 s[2][2];      // raw score tiles [block][kb], written by the asm MFMAs of phase Q, dead once scaled into pe
+  float pe[2][32];     // c.s - c.m, then exp2 of it: element (kb, i) of block x at [16 kb + i]; plain scalars, so the
+                       // register allocator never has to copy or spill part of an MFMA tuple
+  u32x4 pfr[2][2][2];  // P fragments [block][kb][st]: 8 x 16-bit = the B operand of one PV step
+  float mref[2], mthr[2], negmc[2], l0[2], l1[2];
+  float mxc[2][4];     // running maxima: block x, chain c covers s[.][x][c/2][8(c%2) .. +7]
+  const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
+  const float thr_raw = FA_PP_THR / c2;            // the threshold in raw-score units
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    mref[x] = -INFINITY;
+    mthr[x] = -INFINITY;
+    negmc[x] = 0.0f;  // replaced by the first tile's rescale before any use
+    l0[x] = 0.0f;
+    l1[x] = 0.0f;
+  }
+
+  float dbg_a0 = 0.0f, dbg_a1 = 0.0f;
+  bool dbg_done = false;
+  (void)dbg_a0; (void)dbg_a1; (void)dbg_done;
+  // ================= softmax pieces (C = score buffer, x = block) =================
+  // The scores come straight out of asm MFMAs and hipcc pads nothing after an asm statement: a VALU read needs
+  // >= 11 wait states behind the MFMA. Naming the tuples "+v" makes every later reader depend on this statement
+  // (an operand-less s_nop would not stop hipcc from hoisting a reader above it).
+  auto fence_scores = [&]() __attribute__((always_inline)) {
+    asm volatile("s_nop 15" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]));
+  };
+  auto sm_mask = [&](auto xc, const int t) __attribute__((always_inline)) {  // masked iff key > query (kernels.metal:748) or key >= Nk
+    constexpr int x = decltype(xc)::value;
+    const int kv0 = t * BN, qx0 = qw0 + 32 * x;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      int lim = p.Nk - 1 - kv0 - 32 * kb - 4 * h;
+      if (CAUSAL) lim = min(lim, qx0 + r + coff - kv0 - 32 * kb - 4 * h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kpart = (i & 3) + 8 * (i >> 2);
+        s[x][kb][i] = (kpart > lim) ? -INFINITY : s[x][kb][i];
+      }
+    }
+  };
+  // 16 ops per block: ops 0..7 reduce kb = 0 (two interleaved chains), ops 8..15 kb = 1 -- the tuple the
+  // matrix pipe finished LAST is read last (an asm MFMA's result needs >= 11 wait states before a VALU read)
+  auto sm_max_op = [&](auto xc, int k) __attribute__((always_inline)) {
+    constexpr int x = decltype(xc)::value;
+    const int kb = k / 8, c = 2 * kb + (k % 2), stp = (k % 8) / 2, e0 = 8 * (c % 2);
+    const f32x16 &t = s[x][kb];
+    if (stp == 0) mxc[x][c] = fmaxf(fmaxf(t[e0], t[e0 + 1]), t[e0 + 2]);
+    else if (stp < 3) mxc[x][c] = fmaxf(fmaxf(mxc[x][c], t[e0 + 2 * stp + 1]), t[e0 + 2 * stp + 2]);  // -> v_max3_f32
+    else mxc[x][c] = fmaxf(mxc[x][c], t[e0 + 7]);
+  };
+  auto sm_rowmax = [&](auto xc) __attribute__((always_inline)) -> float {
+    constexpr int x = decltype(xc)::value;
+    float mx = fmaxf(fmaxf(mxc[x][0], mxc[x][1]), fmaxf(mxc[x][2], mxc[x][3]));
+    float lo, hi;
+    half_pair(mx, lo, hi);
+    return fmaxf(lo, hi);
+  };
+  // rescale block x to the new reference (O^T of x is complete: no PV MFMA of this tile is pending)
+  auto sm_rescale = [&](auto xc, const float mx) __attribute__((always_inline)) {
+    constexpr int x = decltype(xc)::value;
+    const float m_new = fmaxf(mref[x], mx);
+    const float alpha = __builtin_amdgcn_exp2f((mref[x] - m_new) * c2);  // first tile: exp2(-inf) = 0
+    l0[x] *= alpha;
+    l1[x] *= alpha;
+    asm volatile("s_nop 15\n\ts_nop 7" ::"v"(alpha));  // MFMA write -> accvgpr read; VALU write -> asm read
+    static_for<0, 16 * DB>([&](auto ic) __attribute__((always_inline)) { acc_scale1<NACC, (TIOFF + x * DB) * 16 + decltype(ic)::value>(alpha); });
+    asm volatile("s_nop 3");                           // accvgpr write -> MFMA read as C
+    mref[x] = m_new;
+    mthr[x] = m_new + thr_raw;
+    negmc[x] = -m_new * c2;
+  };
+  // start half: pe = c.s - c.m for all 16 units (the raw tuple dies here); exp2 for units 0..7 (kb = 0).
+  // Row rr of 17: exp(rr-1), fma(rr) -- consecutive stages of a unit sit in different issue gaps
+  auto sm_start_row = [&](auto xc, int rr) __attribute__((always_inline)) {
+    constexpr int x = decltype(xc)::value;
+    if (rr >= 1 && rr - 1 < NU / 2) {
+      const int j = 2 * (rr - 1);
+      pe[x][j] = __builtin_amdgcn_exp2f(pe[x][j]);
+      pe[x][j + 1] = __builtin_amdgcn_exp2f(pe[x][j + 1]);
+      asm volatile("" ::"v"(pe[x][j]), "v"(pe[x][j + 1]));  // pin: keep the work in this gap (inputs only: nothing is padded)
+    }
+    if (rr < NU) {
+      const int u = rr, kb = u / 8, e = 2 * (u % 8), j = 2 * u;
+      pe[x][j] = __builtin_fmaf(s[x][kb][e], c2, negmc[x]);
+      pe[x][j + 1] = __builtin_fmaf(s[x][kb][e + 1], c2, negmc[x]);
+      asm volatile("" ::"v"(pe[x][j]), "v"(pe[x][j + 1]));
+    }
+  };
+  // finish half: exp2 for units 8..15 (kb = 1); row sums and packed P for all. Row rr of 17: sum(rr-1), exp(8+rr) [rr < 8]
+  auto sm_finish_row = [&](auto xc, int rr) __attribute__((always_inline)) {
+    constexpr int x = decltype(xc)::value;
+    if (rr >= 1) {
+      const int u = rr - 1, kb = u / 8, e = 2 * (u % 8), j = 2 * u;
+      l0[x] += pe[x][j];
+      l1[x] += pe[x][j + 1];
+      elem2 pk;
+      pk[0] = (elem)pe[x][j];
+      pk[1] = (elem)pe[x][j + 1];
+      const unsigned w = __builtin_bit_cast(unsigned, pk);
+      asm volatile("" ::"v"(w), "v"(l0[x]), "v"(l1[x]));  // pin
+      pfr[x][kb][e / 8][(e % 8) / 2] = w;
+    }
+    if (rr < NU / 2) {
+      const int j = 2 * (NU / 2 + rr);
+      pe[x][j] = __builtin_amdgcn_exp2f(pe[x][j]);
+      pe[x][j + 1] = __builtin_amdgcn_exp2f(pe[x][j + 1]);
+    }
+  };
+  constexpr int NROW = NU + 1;  // rows per block of either half
+
+  // ================= phase Q: S(A,B) = K.Q^T of the next tile  ||  finish softmax of the current one: pe -> P, l =================
+  // K tile in Kbuf[kbuf]; HAS_QK = false on the wave's last tile (nothing left to score).
+  auto phase_q = [&](auto hasqkc, const int kbuf) __attribute__((always_inline)) {
+    constexpr bool HAS_QK = decltype(hasqkc)::value;
+    constexpr int NF = HAS_QK ? 2 * KS : 0;  // fragments (kb, ks); each feeds 2 MFMAs (block A, block B)
+    constexpr int NG = HAS_QK ? 2 * NF : 1;  // gap groups
+    constexpr int NR = 2 * NROW;             // finish rows of both blocks, interleaved A, B, A, ...
+    const lds_char *Kt = Kbuf + kbuf * TILE;
+    u32x4 kf[NF > 0 ? NF : 1];
+    auto kread = [&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value;
+      kf[f] = lds_read_b128(Kt + (f / KS) * 32 * RB + koff[f % KS]);
+    };
+    if constexpr (HAS_QK) {
+      static_for<0, (LA < NF ? LA : NF)>([&](auto fc) __attribute__((always_inline)) { kread(fc); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    static_for<0, NG>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+#pragma unroll
+      for (int rr = g * NR / NG; rr < (g + 1) * NR / NG; ++rr) {
+        if (rr % 2 == 0) sm_finish_row(std::integral_constant<int, 0>{}, rr / 2);
+        else sm_finish_row(std::integral_constant<int, 1>{}, rr / 2);
+      }
+      if constexpr (HAS_QK) {
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int f = g / 2, x = g % 2, kb = f / KS, ks = f % KS;
+#ifdef FA_PP_QVGPR
+        if constexpr (ks == 0) M::mfma_v0(s[x][kb], kf[f], qv[x][ks]);
+        else M::mfma_v(s[x][kb], kf[f], qv[x][ks]);
+#else
+        mfma_v_qacc<Tag, NACC, NACC_O + 4 * (x * KS + ks), ks == 0>(s[x][kb], kf[f]);
+#endif
+        if constexpr (x == 1 && f + LA < NF) kread(std::integral_constant<int, f + LA>{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // ================= phase P: O(A,B) += V^T.P^T  ||  start softmax of the scores of tile tn: S -> pe =================
+  // V tile in Vbuf[vbuf]. HAS_NEXT = false on the wave's last tile; MASK applies the mask to tile tn first (cold).
+  auto phase_p = [&](auto hasnextc, auto maskc, const int vbuf, const int tn) __attribute__((always_inline)) {
+    constexpr bool HAS_NEXT = decltype(hasnextc)::value, MASK = decltype(maskc)::value;
+    constexpr int NF = 4 * DB;       // fragments (kb, st, db); each feeds 2 MFMAs (block A, block B)
+    constexpr int NG = 2 * NF;       // gap groups = MFMAs
+    constexpr int GH = HAS_NEXT ? (NG >= 32 ? 8 : 4) : 0;  // head groups: row maxima of both blocks, then the decision
+    constexpr int NR = 2 * NROW;     // start rows of both blocks
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, 1>;
+    const lds_char *Vt = Vbuf + vbuf * TILE;
+    if constexpr (HAS_NEXT && MASK) {
+      fence_scores();
+      sm_mask(X0{}, tn);
+      sm_mask(X1{}, tn);
+    }
+    u32x4 vf[NF];
+    auto vread = [&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value;
+      constexpr int kb = f / (2 * DB), st = (f / DB) % 2, db = f % DB;
+      const lds_char *vb = Vt + (32 * kb + 16 * st) * RB + voff[db];
+      const s16x4 lo = lds_read_tr16(vb), hi = lds_read_tr16(vb + 8 * RB);
+      vf[f] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto pv = [&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int f = g / 2, x = g % 2, kb = f / (2 * DB), st = (f / DB) % 2, db = f % DB;
+      acc_mfma<Tag, NACC, TIOFF + x * DB + db>(vf[f], pfr[x][kb][st]);
+      if constexpr (x == 1 && f + LA < NF) vread(std::integral_constant<int, f + LA>{});
+    };
+    static_for<0, (LA < NF ? LA : NF)>([&](auto fc) __attribute__((always_inline)) { vread(fc); });
+    __builtin_amdgcn_sched_barrier(0);
+    // head: maxima (32 ops over GH groups)
+    static_for<0, GH>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+#pragma unroll
+      for (int k = g * 32 / GH; k < (g + 1) * 32 / GH; ++k) {
+        if (k % 2 == 0) sm_max_op(X0{}, k / 2);
+        else sm_max_op(X1{}, k / 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      pv(gc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    FA_DBG_POINT(4);
+    bool rare = false;
+    float mxA = 0.0f, mxB = 0.0f;
+    if constexpr (HAS_NEXT) {
+      mxA = sm_rowmax(X0{});
+      mxB = sm_rowmax(X1{});
+      rare = __builtin_amdgcn_ballot_w64(mxA > mthr[0] || mxB > mthr[1]) != 0;
+    }
+    if (HAS_NEXT && rare) {
+      FA_DBG_POINT(5);
+      // deferred max fired: finish this tile's PV bare, THEN rescale, THEN exponentiate tile tn
+      static_for<GH, NG>([&](auto gc) __attribute__((always_inline)) {
+        pv(gc);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (__builtin_amdgcn_ballot_w64(mxA > mthr[0]) != 0) sm_rescale(X0{}, mxA);
+      if (__builtin_amdgcn_ballot_w64(mxB > mthr[1]) != 0) sm_rescale(X1{}, mxB);
+#pragma unroll
+      for (int rr = 0; rr < NROW; ++rr) {
+        sm_start_row(X0{}, rr);
+        sm_start_row(X1{}, rr);
+      }
+    } else {
+      static_for<GH, NG>([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (HAS_NEXT) {
+#pragma unroll
+          for (int rr = (g - GH) * NR / (NG - GH); rr < (g - GH + 1) * NR / (NG - GH); ++rr) {
+            if (rr % 2 == 0) sm_start_row(X0{}, rr / 2);
+            else sm_start_row(X1{}, rr / 2);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        pv(gc);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using T = std::true_type;
+  using F = std::false_type;
+
+  // ---- pipeline fill: scores of tile 0, then its start half (always masked, always "rare":
+  // the first tile sets the reference)
+  {
+    const lds_char *Kt = Kbuf;
+    static_for<0, 2 * KS>([&](auto fc) __attribute__((always_inline)) {
+      constexpr int f = decltype(fc)::value, kb = f / KS, ks = f % KS;
+      const u32x4 kfr = lds_read_b128(Kt + kb * 32 * RB + koff[ks]);
+#ifdef FA_PP_QVGPR
+      if constexpr (ks == 0) { M::mfma_v0(s[0][kb], kfr, qv[0][ks]); M::mfma_v0(s[1][kb], kfr, qv[1][ks]); }
+      else { M::mfma_v(s[0][kb], kfr, qv[0][ks]); M::mfma_v(s[1][kb], kfr, qv[1][ks]); }
+#else
+      mfma_v_qacc<Tag, NACC, NACC_O + 4 * (0 * KS + ks), ks == 0>(s[0][kb], kfr);
+      mfma_v_qacc<Tag, NACC, NACC_O + 4 * (1 * KS + ks), ks == 0>(s[1][kb], kfr);
+#endif
+    });
+    fence_scores();
+    sm_mask(I0{}, 0);
+    sm_mask(I1{}, 0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      sm_max_op(I0{}, k);
+      sm_max_op(I1{}, k);
+    }
+    sm_rescale(I0{}, sm_rowmax(I0{}));
+    sm_rescale(I1{}, sm_rowmax(I1{}));
+#pragma unroll
+    for (int rr = 0; rr < NROW; ++rr) {
+      sm_start_row(I0{}, rr);
+      sm_start_row(I1{}, rr);
+    }
+  }
+
+  // One iteration t (PAR = t & 1): pe holds tile t (start half done); K(t+1) = Kbuf[PAR^1], V(t) = Vbuf[PAR];
+  // stages K(t+2) -> Kbuf[PAR], V(t+1) -> Vbuf[PAR^1]
+  auto iter = [&](auto parc, const int t) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(parc)::value;
+    using PK = std::integral_constant<int, PAR ^ 1>;
+    using PV = std::integral_constant<int, PAR>;
+#ifdef FA_PP_DIAG  // timing experiments only (results are wrong): 1 = no barrier, 2 = no global loads, 4 = no LDS writes
+    const bool ldk = !(FA_PP_DIAG & 2) && t + 2 < nT, ldv = !(FA_PP_DIAG & 2) && t + 1 < nT;
+#else
+    const bool ldk = t + 2 < nT, ldv = t + 1 < nT;
+#endif
+    if (ldk) load_k(t + 2);
+    if (ldv) load_v(t + 1);
+    if (t < nHot) {                               // hot: tile t+1 exists and needs no mask
+      FA_DBG_POINT(1);
+      phase_q(T{}, PK{});
+      FA_DBG_POINT(2);
+      phase_p(T{}, F{}, PV{}, t + 1);
+      FA_DBG_POINT(3);
+    } else if (t < nTw) {
+      if (t + 1 < nTw) {                          // cold: tile t+1 is masked
+        phase_q(T{}, PK{});
+        phase_p(T{}, T{}, PV{}, t + 1);
+      } else {                                    // this wave's last tile: drain
+        phase_q(F{}, PK{});
+        phase_p(F{}, F{}, PV{}, t + 1);
+      }
+    }
+#ifdef FA_PP_DIAG
+    if (!(FA_PP_DIAG & 4)) {
+      if (ldk || (FA_PP_DIAG & 2)) write_k(PAR);
+      if (ldv || (FA_PP_DIAG & 2)) write_v(PAR ^ 1);
+    }
+    if (!(FA_PP_DIAG & 1)) __syncthreads();
+#else
+    if (ldk) write_k(PAR);
+    if (ldv) write_v(PAR ^ 1);
+    __syncthreads();
+#endif
+  };
+  for (int t = 0; t < nT; t += 2) {
+    iter(I0{}, t);
+    if (t + 1 < nT) iter(I1{}, t + 1);
+  }
+
+  // ---- epilogue: normalise, LSE, O tiles -> LDS -> whole rows, 16 B per lane
+  asm volatile("s_nop 15\n\ts_nop 7");        // last PV MFMA -> accvgpr reads
+  lds_char *Ot = smem + wave * (PP_WM * RB);  // this wave's [64][D] tile (inside the K/V buffers; all reads are done)
+  elem *Og = (elem *)p.o + base;
+  static_for<0, 2>([&](auto xc) __attribute__((always_inline)) {
+    constexpr int x = decltype(xc)::value;
+    float l = l0[x] + l1[x];
+    {
+      float lo, hi;
+      half_pair(l, lo, hi);
+      l = lo + hi;
+    }
+    const float inv_l = 1.0f / l;
+    const int qrow = qw0 + 32 * x + r;
+#ifdef FA_PP_DBGA0
+    if (p.lse != nullptr && qrow < p.N && x == 0) p.lse[(long long)bh * p.N + qrow + 32 * h] = (r & 1) ? dbg_a1 : dbg_a0;
+#else
+    if (p.lse != nullptr && h == 0 && qrow < p.N) p.lse[(long long)bh * p.N + qrow] = mref[x] * p.scale + logf(l);
+#endif
+    static_for<0, DB * 4>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int db = decltype(jc)::value / 4, g4 = decltype(jc)::value % 4;
+      constexpr int R0 = 16 * (TIOFF + x * DB + db) + 4 * g4;
+      elem2 a, b;
+      a[0] = (elem)(acc_read1<NACC, R0 + 0>() * inv_l);
+      a[1] = (elem)(acc_read1<NACC, R0 + 1>() * inv_l);
+      b[0] = (elem)(acc_read1<NACC, R0 + 2>() * inv_l);
+      b[1] = (elem)(acc_read1<NACC, R0 + 3>() * inv_l);
+      u32x2 w;
+      w[0] = __builtin_bit_cast(unsigned, a);
+      w[1] = __builtin_bit_cast(unsigned, b);
+      const int col_b = (32 * db + 8 * g4 + 4 * h) * 2;
+      const int ch = (col_b >> 4) ^ (r & (CPR - 1));
+      lds_write_b64(Ot + (32 * x + r) * RB + (ch << 4) + (col_b & 15), w);
+    });
+  });
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < PP_WM * CPR / 64; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / CPR, ch = idx % CPR;
+    const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPR - 1))) << 4));
+    if (qw0 + row < p.N) *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
+  }
+}
+
+// ---------------------------------------------------------------------------
+bool pp_supported(int dtype, int D) {
+  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_FP8_E4M3) && (D == 64 || D == 128);
+}
+
+template <typename Tag, int D, bool CAUSAL>
+static hipError_t launch_pp_one(const Params &p, hipStream_t s) {
+  const int nQ = (p.N + PP_BM - 1) / PP_BM;
+  const size_t smem = 4 * BN * D * 2;
+  auto kern = fwd_pp_kernel<Tag, D, CAUSAL>;
+  if (smem > 48 * 1024) {
+    hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  Params pp = p;
+  pp.head_group = causal_head_group(p, D, std::is_same<Tag, FP8>::value ? 1 : 2);
+  (void)hipGetLastError();  // do not report an older sticky error as this launch's
+  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
+  return hipGetLastError();
+}
+
+template <typename Tag>
+static hipError_t launch_pp_dt(const Params &p, hipStream_t s) {
+  if (p.D == 64) return p.is_causal ? launch_pp_one<Tag, 64, true>(p, s) : launch_pp_one<Tag, 64, false>(p, s);
+#if FA_PP_TIOFF  // debug builds shift the accumulator map and only fit head_dim 64
+  return hipErrorInvalidValue;
+#else
+  return p.is_causal ? launch_pp_one<Tag, 128, true>(p, s) : launch_pp_one<Tag, 128, false>(p, s);
+#endif
+}
+
+hipError_t launch_pp(const Params &p, int dtype, hipStream_t s) {
+  if (dtype == FA_DTYPE_FP8_E4M3) return launch_pp_dt<FP8>(p, s);
+  return dtype == FA_DTYPE_F16 ? launch_pp_dt<F16>(p, s) : launch_pp_dt<BF16>(p, s);
+}
+
+}  // namespace fa

@@ -66,7 +66,9 @@ template <> struct MT<FP8> {  // e4m3 inputs: converted to bf16 on the way into 
 // v_accvgpr_mov per 32x64 score tile.) Every statement lists the whole range as clobbered, which also
 // makes the kernel descriptor reserve it. hipcc pads no hazards around asm: see the callers' s_nop.
 #define FA_A64 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
+#define FA_A96 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95"
 #define FA_A128 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
+#define FA_A192 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -76,40 +78,62 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+// One asm statement with the clobber list that matches the kernel's owned range a[0 : NACC).
+#define FA_ACC_ASM(NACC, ...)                                  \
+  do {                                                         \
+    if constexpr ((NACC) == 64) asm volatile(__VA_ARGS__ : FA_A64);        \
+    else if constexpr ((NACC) == 96) asm volatile(__VA_ARGS__ : FA_A96);   \
+    else if constexpr ((NACC) == 128) asm volatile(__VA_ARGS__ : FA_A128); \
+    else asm volatile(__VA_ARGS__ : FA_A192);                  \
+  } while (0)
+
+template <typename Tag> struct MfmaOp { static constexpr bool is_f16 = std::is_same<Tag, F16>::value; };
+
 // a[16*TI .. 16*TI+15] += A(frag) * B(frag)   (32x32x16, A/B in VGPRs)
 template <typename Tag, int NACC, int TI>
 __device__ __forceinline__ void acc_mfma(u32x4 a, u32x4 b) {
   constexpr int lo = 16 * TI, hi = lo + 15;
   static_assert(hi < NACC, "accumulator tuple out of range");
-#define FA_ACC_MFMA(OP, CL) asm volatile(OP " a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(lo), "i"(hi) : CL)
-  if constexpr (std::is_same<Tag, F16>::value) {
-    if constexpr (NACC == 64) FA_ACC_MFMA("v_mfma_f32_32x32x16_f16", FA_A64);
-    else FA_ACC_MFMA("v_mfma_f32_32x32x16_f16", FA_A128);
+#ifdef FA_DBG_NOP
+#define FA_DBG_PRE "s_nop 15\n\t"
+#define FA_DBG_POST "\n\ts_nop 15"
+#else
+#define FA_DBG_PRE ""
+#define FA_DBG_POST ""
+#endif
+  if constexpr (MfmaOp<Tag>::is_f16) FA_ACC_ASM(NACC, FA_DBG_PRE "v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" FA_DBG_POST ::"v"(a), "v"(b), "i"(lo), "i"(hi));
+  else FA_ACC_ASM(NACC, FA_DBG_PRE "v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" FA_DBG_POST ::"v"(a), "v"(b), "i"(lo), "i"(hi));
+}
+// d (VGPR tuple) = A(frag, VGPR) * B(a[QR .. QR+3], asm-owned) [+ d]: the score product with Q parked in the accumulation file
+template <typename Tag, int NACC, int QR, bool FIRST>
+__device__ __forceinline__ void mfma_v_qacc(f32x16 &d, u32x4 a) {
+  static_assert(QR + 3 < NACC, "Q fragment out of range");
+  if constexpr (FIRST) {
+    if constexpr (MfmaOp<Tag>::is_f16) FA_ACC_ASM(NACC, "v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(QR), "i"(QR + 3));
+    else FA_ACC_ASM(NACC, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "i"(QR), "i"(QR + 3));
   } else {
-    if constexpr (NACC == 64) FA_ACC_MFMA("v_mfma_f32_32x32x16_bf16", FA_A64);
-    else FA_ACC_MFMA("v_mfma_f32_32x32x16_bf16", FA_A128);
+    if constexpr (MfmaOp<Tag>::is_f16) FA_ACC_ASM(NACC, "v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(QR), "i"(QR + 3));
+    else FA_ACC_ASM(NACC, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(QR), "i"(QR + 3));
   }
-#undef FA_ACC_MFMA
 }
 template <int NACC, int R>
 __device__ __forceinline__ void acc_zero1() {
-  if constexpr (NACC == 64) asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"i"(R) : FA_A64);
-  else asm volatile("v_accvgpr_write_b32 a%c0, 0" ::"i"(R) : FA_A128);
+  FA_ACC_ASM(NACC, "v_accvgpr_write_b32 a%c0, 0" ::"i"(R));
+}
+template <int NACC, int R>
+__device__ __forceinline__ void acc_write1(unsigned v) {
+  FA_ACC_ASM(NACC, "v_accvgpr_write_b32 a%c1, %0" ::"v"(v), "i"(R));
 }
 template <int NACC, int R>
 __device__ __forceinline__ float acc_read1() {
   float f;
-  if constexpr (NACC == 64) asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(f) : "i"(R) : FA_A64);
-  else asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(f) : "i"(R) : FA_A128);
+  FA_ACC_ASM(NACC, "v_accvgpr_read_b32 %0, a%c1" : "=v"(f) : "i"(R));
   return f;
 }
 template <int NACC, int R>
 __device__ __forceinline__ void acc_scale1(float alpha) {  // a[R] *= alpha (per lane)
   float t;
-#define FA_ACC_SCALE(CL) asm volatile("v_accvgpr_read_b32 %0, a%c2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c2, %0" : "=&v"(t) : "v"(alpha), "i"(R) : CL)
-  if constexpr (NACC == 64) FA_ACC_SCALE(FA_A64);
-  else FA_ACC_SCALE(FA_A128);
-#undef FA_ACC_SCALE
+  FA_ACC_ASM(NACC, "v_accvgpr_read_b32 %0, a%c2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a%c2, %0" : "=&v"(t) : "v"(alpha), "i"(R));
 }
 
 constexpr int BM = 128;      // query rows per workgroup

@@ -251,6 +251,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     u32x4 aop[NM > 0 ? NM : 1];
     auto opread = [&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
+#ifdef FA_PP_DIAG
+      if constexpr ((FA_PP_DIAG & 8) != 0) {  // no LDS reads: operands are whatever the registers hold
+        asm volatile("" : "=v"(aop[g]));
+        return;
+      }
+#endif
       if constexpr (g < NQK) {
         aop[g] = lds_read_b128(Kt + (g / KS) * 32 * RB + koff[g % KS]);
       } else {
@@ -263,6 +269,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     };
     auto domfma = [&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
+#ifdef FA_PP_DIAG
+      if constexpr ((FA_PP_DIAG & 32) != 0) {  // no MFMAs
+        asm volatile("" ::"v"(aop[g]));
+        if constexpr (g < NQK && (g % KS) == 0) asm volatile("" : "=v"(s[Y][g / KS]));
+        return;
+      }
+#endif
       if constexpr (g < NQK) {
         if constexpr ((g % KS) == 0) M::mfma_v0(s[Y][g / KS], aop[g], qf[Y][g % KS]);
         else M::mfma_v(s[Y][g / KS], aop[g], qf[Y][g % KS]);
@@ -390,12 +403,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     constexpr int PAR = decltype(parc)::value;
     using PV = std::integral_constant<int, PAR>;
     using PK = std::integral_constant<int, PAR ^ 1>;
+#ifdef FA_PP_DIAG  // timing experiments only (results are wrong): 1 = no barrier, 2 = no global loads, 4 = no LDS writes
+    const bool ldk = !(FA_PP_DIAG & 2) && t + 2 < nT, ldv = !(FA_PP_DIAG & 2) && t + 1 < nT;
+#else
     const bool ldk = t + 2 < nT, ldv = t + 1 < nT;
+#endif
     if (ldk) load_k(t + 2);
     if (ldv) load_v(t + 1);
     if (t < nClean) {                                       // hot: no masks, static LDS buffers
+#if defined(FA_PP_DIAG) && (FA_PP_DIAG & 16)               // timing experiment: no softmax
+      slot(PV{}, PK{}, I1{}, T{}, T{}, F{}, F{}, t);
+      slot(PV{}, PK{}, I0{}, T{}, T{}, F{}, F{}, t + 1);
+#else
       slot(PV{}, PK{}, I1{}, T{}, T{}, T{}, F{}, t);        // QK^T(A,t+1), PV(A,t) || softmax(B,t)
       slot(PV{}, PK{}, I0{}, T{}, T{}, T{}, F{}, t + 1);    // QK^T(B,t+1), PV(B,t) || softmax(A,t+1)
+#endif
     } else if (t < nTw) {                                   // cold: masks always applied, runtime LDS buffers
       const int vb = PAR, kb = PAR ^ 1;
       if (t + 1 < nTw) {
@@ -406,9 +428,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
         slot(vb, kb, I0{}, T{}, F{}, F{}, F{}, t);          // PV(B,t)
       }
     }
+#ifdef FA_PP_DIAG
+    if (!(FA_PP_DIAG & 4)) {
+      if (ldk || (FA_PP_DIAG & 2)) write_k(PAR);
+      if (ldv || (FA_PP_DIAG & 2)) write_v(PAR ^ 1);
+    }
+    if (!(FA_PP_DIAG & 1)) __syncthreads();
+#else
     if (ldk) write_k(PAR);
     if (ldv) write_v(PAR ^ 1);
     __syncthreads();
+#endif
   };
   for (int t = 0; t < nT; t += 2) {
     iter(I0{}, t);
