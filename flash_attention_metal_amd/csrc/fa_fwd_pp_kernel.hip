@@ -64,7 +64,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
 #endif
   constexpr int TIOFF = FA_PP_TIOFF;        // debug: leave the first TIOFF accumulator tuples unused
   constexpr int NACC_O = (2 * DB + TIOFF) * 16;  // O^T of block x, d block db = a[16(x DB + db) ..+15]
-  constexpr int NACC = (TIOFF ? 192 : NACC_O + 2 * KS * 4); // + Q fragment (x, ks) = a[NACC_O + 4(x KS + ks) ..+3]
+  constexpr int NACC_Q = NACC_O + 2 * KS * 4;    // + Q fragment (x, ks) = a[NACC_O + 4(x KS + ks) ..+3]
+  constexpr bool ASM_STAGE = !std::is_same<Tag, FP8>::value;  // 16-bit inputs: the loop's K/V staging registers are asm-owned too
+  constexpr int NST = ASM_STAGE ? 2 * (BN * (D * 2 / 16) / NTHREADS) * 4 : 0;  // a[NACC_Q + 4 i ..+3] = staged chunk i (K chunks, then V chunks)
+  constexpr int NACC = TIOFF ? 224 : NACC_Q + NST;
   constexpr int TILE = BN * RB;             // bytes of one K (or V) tile in LDS
   constexpr bool IS_FP8 = std::is_same<Tag, FP8>::value;
   constexpr int GB = IS_FP8 ? 1 : 2;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
   constexpr int NCH = BN * GCPR / NTHREADS; // staged 16-byte global chunks per thread per tile
   constexpr int LA = FA_PP_LA;
   constexpr int NU = 16;                    // per block and tile: 16 units of two scores each (unit u: kb = u/8, e = 2(u%8))
-  static_assert(NACC == 96 || NACC == 192, "head_dim 64 or 128");
+  static_assert(TIOFF || NACC == 96 || NACC == 112 || NACC == 192 || NACC == 224, "head_dim 64 or 128");
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
@@ -152,31 +155,32 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)t * GTILE + st_g[i], 0, 0);
   };
+  auto write_k1 = [&](int buf, int i) __attribute__((always_inline)) {  // one staged chunk of the K tile
+    if constexpr (IS_FP8) {
+      lds_write_b128(Kbuf + buf * TILE + st_k[i], fp8x8_to_bf16(u32x2{kst[i][0], kst[i][1]}));
+      lds_write_b128(Kbuf + buf * TILE + st_k1[i], fp8x8_to_bf16(u32x2{kst[i][2], kst[i][3]}));
+    } else {
+      lds_write_b128(Kbuf + buf * TILE + st_k[i], kst[i]);
+    }
+  };
+  auto write_v1 = [&](int buf, int i) __attribute__((always_inline)) {
+    if constexpr (IS_FP8) {
+      lds_write_b128(Vbuf + buf * TILE + st_v[i], fp8x8_to_bf16(u32x2{vst[i][0], vst[i][1]}));
+      lds_write_b128(Vbuf + buf * TILE + st_v1[i], fp8x8_to_bf16(u32x2{vst[i][2], vst[i][3]}));
+    } else {
+      lds_write_b128(Vbuf + buf * TILE + st_v[i], vst[i]);
+    }
+  };
   auto write_k = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      if constexpr (IS_FP8) {
-        lds_write_b128(Kbuf + buf * TILE + st_k[i], fp8x8_to_bf16(u32x2{kst[i][0], kst[i][1]}));
-        lds_write_b128(Kbuf + buf * TILE + st_k1[i], fp8x8_to_bf16(u32x2{kst[i][2], kst[i][3]}));
-      } else {
-        lds_write_b128(Kbuf + buf * TILE + st_k[i], kst[i]);
-      }
-    }
+    for (int i = 0; i < NCH; ++i) write_k1(buf, i);
   };
   auto write_v = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      if constexpr (IS_FP8) {
-        lds_write_b128(Vbuf + buf * TILE + st_v[i], fp8x8_to_bf16(u32x2{vst[i][0], vst[i][1]}));
-        lds_write_b128(Vbuf + buf * TILE + st_v1[i], fp8x8_to_bf16(u32x2{vst[i][2], vst[i][3]}));
-      } else {
-        lds_write_b128(Vbuf + buf * TILE + st_v[i], vst[i]);
-      }
-    }
+    for (int i = 0; i < NCH; ++i) write_v1(buf, i);
   };
+  constexpr int NPIECE = 2 * NCH;  // LDS-write pieces of one iteration's staging: K chunks, then V chunks
 
-  u32x4 qv[2][KS];  // (FA_PP_QVGPR builds only: Q fragments in VGPRs)
-  (void)qv;
   // ---- prologue: Q fragments -> accumulation file; K(0), V(0), K(1) -> LDS; O = 0
   static_for<0, NACC_O>([&](auto ic) __attribute__((always_inline)) { acc_zero1<NACC, decltype(ic)::value>(); });
   {
@@ -187,25 +191,30 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     for (int i = 0; i < NCH; ++i) k1[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)GTILE + st_g[i], 0, 0);
     load_k(0);
     load_v(0);
-    // Q fragment (x, ks): lane (r,h) holds Q[qw0 + 32x + r][16ks + 8h .. +7] (B operand of K.Q^T); rows >= N read as zero
-    static_for<0, 2 * KS>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int x = decltype(ic)::value / KS, ks = decltype(ic)::value % KS;
+    // Q fragment (x, ks): lane (r,h) holds Q[qw0 + 32x + r][16ks + 8h .. +7] (B operand of K.Q^T); rows >= N read as zero.
+    // All loads first, then the moves into the accumulation file (each move waits for its load).
+    u32x4 qtmp[2 * KS];
+#pragma unroll
+    for (int i = 0; i < 2 * KS; ++i) {
+      const int x = i / KS, ks = i % KS;
       const unsigned row = (unsigned)(qw0 + 32 * x + r);
-      u32x4 q;
       if constexpr (IS_FP8) {
         const u32x2 q8 = __builtin_amdgcn_raw_buffer_load_b64(rq, row * GRB + (2 * ks + h) * 8, 0, 0);
-        q = fp8x8_to_bf16(q8);
+        qtmp[i] = fp8x8_to_bf16(q8);
       } else {
-        q = __builtin_amdgcn_raw_buffer_load_b128(rq, row * RB + (2 * ks + h) * 16, 0, 0);
+        qtmp[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, row * RB + (2 * ks + h) * 16, 0, 0);
       }
+    }
+    static_for<0, 2 * KS>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
 #ifdef FA_PP_QVGPR
-      qv[x][ks] = q;
+      qv[i / KS][i % KS] = qtmp[i];
 #else
-      constexpr int R0 = NACC_O + 4 * (x * KS + ks);
-      acc_write1<NACC, R0 + 0>(q[0]);
-      acc_write1<NACC, R0 + 1>(q[1]);
-      acc_write1<NACC, R0 + 2>(q[2]);
-      acc_write1<NACC, R0 + 3>(q[3]);
+      constexpr int R0 = NACC_O + 4 * i;
+      acc_write1<NACC, R0 + 0>(qtmp[i][0]);
+      acc_write1<NACC, R0 + 1>(qtmp[i][1]);
+      acc_write1<NACC, R0 + 2>(qtmp[i][2]);
+      acc_write1<NACC, R0 + 3>(qtmp[i][3]);
 #endif
     });
     write_k(0);
@@ -369,7 +378,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
 
   // ================= phase P: O(A,B) += V^T.P^T  ||  start softmax of the scores of tile tn: S -> pe =================
   // V tile in Vbuf[vbuf]. HAS_NEXT = false on the wave's last tile; MASK applies the mask to tile tn first (cold).
-  auto phase_p = [&](auto hasnextc, auto maskc, const int vbuf, const int tn) __attribute__((always_inline)) {
+  // `stage(i)` writes piece i of the NEXT tiles' staging to LDS (buffers nobody reads during this iteration): spread
+  // over the gaps of the phase body, because 4 waves storing a whole K+V tile back to back in front of the barrier
+  // is an exposed LDS-store burst (measured: 20 % of the head_dim-128 loop).
+  auto phase_p = [&](auto hasnextc, auto maskc, const int vbuf, const int tn, auto &&stage) __attribute__((always_inline)) {
     constexpr bool HAS_NEXT = decltype(hasnextc)::value, MASK = decltype(maskc)::value;
     constexpr int NF = 4 * DB;       // fragments (kb, st, db); each feeds 2 MFMAs (block A, block B)
     constexpr int NG = 2 * NF;       // gap groups = MFMAs
@@ -426,6 +438,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
         pv(gc);
         __builtin_amdgcn_sched_barrier(0);
       });
+      static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { stage(ic); });
       if (__builtin_amdgcn_ballot_w64(mxA > mthr[0]) != 0) sm_rescale(X0{}, mxA);
       if (__builtin_amdgcn_ballot_w64(mxB > mthr[1]) != 0) sm_rescale(X1{}, mxB);
 #pragma unroll
@@ -445,6 +458,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
           __builtin_amdgcn_sched_barrier(0);
         }
         pv(gc);
+        {  // staging pieces ride in the later gaps (the loads were issued at the start of the iteration)
+          constexpr int G0 = GH + (NG - GH) / 4, GS = NG - G0;  // first quarter of the body left alone
+          if constexpr (g >= G0) {
+            static_for<(g - G0) * NPIECE / GS, (g - G0 + 1) * NPIECE / GS>([&](auto ic) __attribute__((always_inline)) { stage(ic); });
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -493,39 +512,59 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     constexpr int PAR = decltype(parc)::value;
     using PK = std::integral_constant<int, PAR ^ 1>;
     using PV = std::integral_constant<int, PAR>;
-#ifdef FA_PP_DIAG  // timing experiments only (results are wrong): 1 = no barrier, 2 = no global loads, 4 = no LDS writes
-    const bool ldk = !(FA_PP_DIAG & 2) && t + 2 < nT, ldv = !(FA_PP_DIAG & 2) && t + 1 < nT;
-#else
-    const bool ldk = t + 2 < nT, ldv = t + 1 < nT;
-#endif
-    if (ldk) load_k(t + 2);
-    if (ldv) load_v(t + 1);
+    // K(t+2) -> Kbuf[PAR], V(t+1) -> Vbuf[PAR^1]: both buffers are idle during this iteration. Issued and written
+    // unconditionally: a tile past the end of the head loads as zero through the descriptor and is never read.
+    // 16-bit inputs: the staged chunks travel global -> asm-owned accumulation registers -> LDS, so hipcc can neither
+    // park them in VGPRs nor wait for them at the top of the iteration (it did: a vmcnt(0) right behind the loads,
+    // the whole memory latency exposed once per iteration). Piece i waits with a counted vmcnt for its own chunk only.
+    // Chunk i of a tile sits NTHREADS*16 bytes behind chunk i-1 in global memory and ROWS_PER_CHUNK rows lower in
+    // the LDS image with the same swizzle (the swizzle period divides ROWS_PER_CHUNK): one per-lane address each,
+    // the rest is a scalar / immediate offset.
+    constexpr int ROWS_PER_CHUNK = NTHREADS / GCPR;
+    if constexpr (ASM_STAGE) {
+      const unsigned gk = (unsigned)(t + 2) * GTILE + st_g[0], gv = (unsigned)(t + 1) * GTILE + st_g[0];
+      static_for<0, NCH>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        acc_buffer_load_b128<NACC, NACC_Q + 4 * i>(rk, gk, (unsigned)(i * NTHREADS * 16));
+      });
+      static_for<0, NCH>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        acc_buffer_load_b128<NACC, NACC_Q + 4 * (NCH + i)>(rv, gv, (unsigned)(i * NTHREADS * 16));
+      });
+    } else {
+      load_k(t + 2);
+      load_v(t + 1);
+    }
+    auto stage = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (ASM_STAGE) {
+        lds_char *dst = (i < NCH) ? Kbuf + st_k[0] : Vbuf + st_v[0];
+        constexpr int OFF = ((i < NCH) ? PAR : (PAR ^ 1)) * TILE + (i % NCH) * ROWS_PER_CHUNK * RB;
+        acc_lds_write_b128<NACC, NACC_Q + 4 * i, NPIECE - 1 - i, OFF>((unsigned)(__UINTPTR_TYPE__)dst);
+      } else {
+        if constexpr (i < NCH) write_k1(PAR, i);
+        else write_v1(PAR ^ 1, i - NCH);
+      }
+    };
     if (t < nHot) {                               // hot: tile t+1 exists and needs no mask
       FA_DBG_POINT(1);
       phase_q(T{}, PK{});
       FA_DBG_POINT(2);
-      phase_p(T{}, F{}, PV{}, t + 1);
+      phase_p(T{}, F{}, PV{}, t + 1, stage);
       FA_DBG_POINT(3);
     } else if (t < nTw) {
       if (t + 1 < nTw) {                          // cold: tile t+1 is masked
         phase_q(T{}, PK{});
-        phase_p(T{}, T{}, PV{}, t + 1);
+        phase_p(T{}, T{}, PV{}, t + 1, stage);
       } else {                                    // this wave's last tile: drain
         phase_q(F{}, PK{});
-        phase_p(F{}, F{}, PV{}, t + 1);
+        phase_p(F{}, F{}, PV{}, t + 1, stage);
       }
+    } else {                                      // this wave is done (causal): it only keeps staging for the others
+      static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { stage(ic); });
     }
-#ifdef FA_PP_DIAG
-    if (!(FA_PP_DIAG & 4)) {
-      if (ldk || (FA_PP_DIAG & 2)) write_k(PAR);
-      if (ldv || (FA_PP_DIAG & 2)) write_v(PAR ^ 1);
-    }
-    if (!(FA_PP_DIAG & 1)) __syncthreads();
-#else
-    if (ldk) write_k(PAR);
-    if (ldv) write_v(PAR ^ 1);
+    if constexpr (ASM_STAGE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not count the asm LDS stores
     __syncthreads();
-#endif
   };
   for (int t = 0; t < nT; t += 2) {
     iter(I0{}, t);

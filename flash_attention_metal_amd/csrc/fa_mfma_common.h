@@ -67,8 +67,10 @@ template <> struct MT<FP8> {  // e4m3 inputs: converted to bf16 on the way into 
 // makes the kernel descriptor reserve it. hipcc pads no hazards around asm: see the callers' s_nop.
 #define FA_A64 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
 #define FA_A96 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95"
+#define FA_A112 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111"
 #define FA_A128 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
 #define FA_A192 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"
+#define FA_A224 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223"
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -79,13 +81,18 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 // One asm statement with the clobber list that matches the kernel's owned range a[0 : NACC).
-#define FA_ACC_ASM(NACC, ...)                                  \
-  do {                                                         \
-    if constexpr ((NACC) == 64) asm volatile(__VA_ARGS__ : FA_A64);        \
-    else if constexpr ((NACC) == 96) asm volatile(__VA_ARGS__ : FA_A96);   \
-    else if constexpr ((NACC) == 128) asm volatile(__VA_ARGS__ : FA_A128); \
-    else asm volatile(__VA_ARGS__ : FA_A192);                  \
+#define FA_ACC_ASM_(NACC, PRE, ...)                                           \
+  do {                                                                        \
+    if constexpr ((NACC) == 64) asm volatile(__VA_ARGS__ : PRE FA_A64);       \
+    else if constexpr ((NACC) == 96) asm volatile(__VA_ARGS__ : PRE FA_A96);  \
+    else if constexpr ((NACC) == 112) asm volatile(__VA_ARGS__ : PRE FA_A112); \
+    else if constexpr ((NACC) == 128) asm volatile(__VA_ARGS__ : PRE FA_A128); \
+    else if constexpr ((NACC) == 192) asm volatile(__VA_ARGS__ : PRE FA_A192); \
+    else asm volatile(__VA_ARGS__ : PRE FA_A224);                             \
   } while (0)
+#define FA_ACC_ASM(NACC, ...) FA_ACC_ASM_(NACC, , __VA_ARGS__)
+#define FA_MEM_CLOBBER "memory",
+#define FA_ACC_ASM_MEM(NACC, ...) FA_ACC_ASM_(NACC, FA_MEM_CLOBBER, __VA_ARGS__)
 
 template <typename Tag> struct MfmaOp { static constexpr bool is_f16 = std::is_same<Tag, F16>::value; };
 
@@ -115,6 +122,19 @@ __device__ __forceinline__ void mfma_v_qacc(f32x16 &d, u32x4 a) {
     if constexpr (MfmaOp<Tag>::is_f16) FA_ACC_ASM(NACC, "v_mfma_f32_32x32x16_f16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(QR), "i"(QR + 3));
     else FA_ACC_ASM(NACC, "v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "i"(QR), "i"(QR + 3));
   }
+}
+// global -> a[R..R+3] (16 bytes per lane) through a buffer descriptor. hipcc does not count an asm load: the
+// caller waits with acc_lds_write_b128's vmcnt (loads complete in issue order).
+template <int NACC, int R>
+__device__ __forceinline__ void acc_buffer_load_b128(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  static_assert(R + 3 < NACC, "staging registers out of range");
+  FA_ACC_ASM(NACC, "buffer_load_dwordx4 a[%c3:%c4], %0, %1, %2 offen" ::"v"(voff), "s"(rsrc), "s"(soff), "i"(R), "i"(R + 3));
+}
+// wait until at most PENDING younger vector-memory operations are outstanding, then LDS[addr + OFF] = a[R..R+3]
+template <int NACC, int R, int PENDING, int OFF>
+__device__ __forceinline__ void acc_lds_write_b128(unsigned lds_addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+  FA_ACC_ASM_MEM(NACC, "s_waitcnt vmcnt(%c3)\n\tds_write_b128 %0, a[%c1:%c2] offset:%c4" ::"v"(lds_addr), "i"(R), "i"(R + 3), "i"(PENDING), "i"(OFF));
 }
 template <int NACC, int R>
 __device__ __forceinline__ void acc_zero1() {
