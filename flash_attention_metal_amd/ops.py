@@ -89,12 +89,14 @@ def flash_attention_forward(
     out_dtype = torch.bfloat16 if fa_dtype == 3 else q.dtype
     if out is None:
         out = torch.empty_strided((B, H, N, D), q.stride(), dtype=out_dtype, device=q.device)
-    elif out.dtype != out_dtype or out.shape != q.shape or _strides(out) != (bs, hs):
-        raise ValueError("out must match q's shape/strides (and be bf16 for fp8 inputs)")
+    elif (not out.is_cuda or out.device != q.device or out.dtype != out_dtype or out.shape != q.shape
+          or _strides(out) != (bs, hs)):
+        raise ValueError("out must be a device tensor with q's shape/strides (bf16 for fp8 inputs)")
     if return_lse and lse is None:
         lse = torch.empty((B, H, N), dtype=torch.float32, device=q.device)
-    if lse is not None and (lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != B * H * N):
-        raise ValueError("lse must be contiguous fp32 [B,H,N]")
+    if lse is not None and (not lse.is_cuda or lse.device != q.device or lse.dtype != torch.float32
+                            or not lse.is_contiguous() or lse.numel() != B * H * N):
+        raise ValueError("lse must be contiguous fp32 [B,H,N] on q's device")
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     if stream is None:
@@ -128,8 +130,15 @@ def _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream):
     out_dtype = torch.bfloat16 if fa_dtype == 3 else q.dtype
     if out is None:
         out = torch.empty_strided((B, Hq, Nq, D), q.stride(), dtype=out_dtype, device=q.device)
+    elif (not out.is_cuda or out.device != q.device or out.dtype != out_dtype or out.shape != q.shape
+          or _strides(out) != (qbs, qhs)):
+        # the kernel writes O with q's strides: anything else lands in the wrong place or out of bounds
+        raise ValueError("out must be a device tensor with q's shape/strides (bf16 for fp8 inputs)")
     if return_lse and lse is None:
         lse = torch.empty((B, Hq, Nq), dtype=torch.float32, device=q.device)
+    if lse is not None and (not lse.is_cuda or lse.device != q.device or lse.dtype != torch.float32
+                            or not lse.is_contiguous() or lse.numel() != B * Hq * Nq):
+        raise ValueError("lse must be contiguous fp32 [B,Hq,Nq] on q's device")
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     if stream is None:

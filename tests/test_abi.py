@@ -88,6 +88,23 @@ def test_bad_arguments_are_rejected_before_launch(fa):
     assert call(dtype=3, hs=128 * 64 + 8) == -1  # fp8 heads must stay 16-byte aligned
 
 
+def test_ex_and_bwd_reject_bad_strides_and_oversized_grids(fa):
+    # fa_fwd_ex / fa_bwd carry the same overflow and stride guards as fa_fwd
+    lib = fa.load_library()
+    P = ctypes.c_void_p
+    ok = P(0x1000)
+    big = 1 << 30
+    # B*Hq*ceil(Nq/128) must fit an int
+    assert lib.fa_fwd_ex(ok, ok, ok, ok, None, 65536, 65536, 65536, 128, 128, 64, 0.125, 65536 * 128 * 64, 128 * 64,
+                         65536 * 128 * 64, 128 * 64, 0, 2, None) == -1 and b"grid" in lib.fa_last_error()
+    assert lib.fa_fwd_ex(ok, ok, ok, ok, None, 2, 2, 2, 128, 128, 64, 0.125, -16384, 8192, 16384, 8192, 0, 2, None) == -1
+    f = P(0x2000)
+    assert lib.fa_bwd(ok, ok, ok, ok, ok, f, f, f, f, f, 65536, 65536, 128, 64, 0.125, 65536 * 8192, 8192, 0, 2, None) == -1 \
+        and b"grid" in lib.fa_last_error()
+    assert lib.fa_bwd(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 2, 128, 64, 0.125, -16384, 8192, 0, 2, None) == -1
+    assert big > 0
+
+
 def test_operator_refuses_cpu_tensors(fa):
     import torch
 

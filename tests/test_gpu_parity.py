@@ -407,6 +407,25 @@ def test_error_behaviour_on_device(fa):
         fa.flash_attention_forward(y.bfloat16(), y.bfloat16(), y.bfloat16(), scale=-1.0)
     with pytest.raises(ValueError):
         fa.flash_attention_forward(y, y[:, :, :64], y)
+    # caller-supplied out / lse are validated on BOTH entry points (square and generalised): wrong strides, dtype,
+    # size or device would make the kernel write out of place
+    q = torch.zeros(2, 4, 128, 64, dtype=torch.bfloat16, device="cuda")
+    kv = torch.zeros(2, 2, 256, 64, dtype=torch.bfloat16, device="cuda")
+    qs = torch.zeros(2, 4, 136, 64, dtype=torch.bfloat16, device="cuda")[:, :, :128]  # strided q
+    for qq, kk in ((q, q), (q, kv), (qs, kv)):
+        with pytest.raises(ValueError):
+            fa.flash_attention_forward(qq, kk, kk, out=torch.empty(2, 4, 128, 64, dtype=torch.float16, device="cuda"))
+        with pytest.raises(ValueError):
+            fa.flash_attention_forward(qq, kk, kk, out=torch.empty(2, 4, 64, 64, dtype=torch.bfloat16, device="cuda"))
+        with pytest.raises(ValueError):
+            fa.flash_attention_forward(qq, kk, kk, lse=torch.empty(2, 4, 64, dtype=torch.float32, device="cuda"))
+        with pytest.raises(ValueError):
+            fa.flash_attention_forward(qq, kk, kk, lse=torch.empty(2, 4, 128, dtype=torch.float16, device="cuda"))
+        with pytest.raises(ValueError):
+            fa.flash_attention_forward(qq, kk, kk, out=torch.empty(2, 4, 128, 64, dtype=torch.bfloat16))  # CPU tensor
+    with pytest.raises(ValueError):  # contiguous out for a strided q
+        fa.flash_attention_forward(qs, kv, kv, out=torch.empty(2, 4, 128, 64, dtype=torch.bfloat16, device="cuda"))
+    torch.cuda.synchronize()
 
 
 # --------------------------------------------------------------------------
@@ -480,6 +499,28 @@ def test_config5_full_fp8(fa, oracle_mod):  # seqlen=8192, D=64, fp8 in / fp32 a
         o64, l64 = oracle_mod.attn_rows_f64(qh, kh, vh, rows, True)
         assert np.abs(o[b, h].float().cpu().numpy()[rows] - o64).max() < TOL_O["bf16"]
         assert np.abs(lse[b, h].cpu().numpy()[rows] - l64).max() < TOL_LSE["bf16"]
+
+
+def test_config4_sharded_equals_unsharded_bit_for_bit(fa, oracle_mod):
+    # BASELINE configs[3] shards (batch, head) over 8 GPUs. The shards must be the SAME computation: here the
+    # 8 shards of a reduced-batch config-4 tensor (B=8 -> 8 shards of 2 heads each, N=4096, D=128, bf16 causal) are
+    # computed one by one on this GPU (as 8 ranks would, flash_attention_metal_amd.shard.shard_heads) and compared bit
+    # for bit with the unsharded call.
+    import torch
+
+    from flash_attention_metal_amd.shard import shard_heads
+
+    B, H, N, D, world = 8, 2, 4096, 128, 8
+    g = torch.Generator(device="cuda").manual_seed(4)
+    q, k, v = (torch.rand(B, H, N, D, generator=g, device="cuda").mul_(2).sub_(1).to(torch.bfloat16) for _ in range(3))
+    o_all, l_all = fa.flash_attention_forward(q, k, v, is_causal=True)
+    qf, kf, vf = (x.view(1, B * H, N, D) for x in (q, k, v))
+    for rank in range(world):
+        lo, hi = shard_heads(B * H, world, rank)
+        o_r, l_r = fa.flash_attention_forward(qf[:, lo:hi].contiguous(), kf[:, lo:hi].contiguous(), vf[:, lo:hi].contiguous(),
+                                              is_causal=True)
+        assert torch.equal(o_r[0], o_all.view(B * H, N, D)[lo:hi]) and torch.equal(l_r[0], l_all.view(B * H, N)[lo:hi])
+    torch.cuda.synchronize()
 
 
 def test_config4_per_gpu_slice_full(fa, oracle_mod):  # seqlen=16384, D=128, bf16 causal; one GPU's 32 (b,h) slices

@@ -77,3 +77,32 @@ def test_single_rank_needs_no_process_group():
         for k, v in env_backup.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def test_bench_entry_as_typed_spawns_ranks_without_a_launcher():
+    # `python bench.py --gpus N` typed without torch.distributed.run must work. The parent touches
+    # no GPU: it spawns N fresh children (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set before they import torch), waits,
+    # and relays rank 0's JSON line. Rehearsed here on CPU over gloo (the control plane is the same code).
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["MASTER_PORT"] = "29541"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--cpu-gloo-rehearsal"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(line) == 1  # ONE JSON line, from rank 0
+    r = json.loads(line[0])
+    assert r["n_gpus"] == 2 and r["backend"] == "gloo" and r["slices_rank0"] == [0, 64] and r["slices_total"] == 128
+    assert r["units_per_s"] == pytest.approx((64 * 3 * 2) / 0.002)  # all ranks' units / the slowest rank's time
+
+
+def test_bench_parent_process_never_imports_torch_or_the_library():
+    # the spawn parent must not initialise a GPU: no module-level import of torch / the kernel library, and the
+    # spawner itself neither touches torch nor execs anything
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    top_imports = [l for l in src.splitlines() if l.startswith(("import ", "from "))]
+    assert top_imports and not any("torch" in l or "flash_attention_metal_amd" in l for l in top_imports)
+    body = src[src.index("def spawn_ranks"):src.index("def timed_launches")]
+    code = "\n".join(l for l in body.splitlines() if not l.strip().startswith(("#", '"""')) and "imports neither" not in l)
+    assert "import torch" not in code and "torch." not in code and "os.exec" not in code and "subprocess.Popen" in code
+    main = src[src.index("def main()"):]
+    assert main.index("return spawn_ranks(args)") < main.index("import torch")  # spawn decision comes first
