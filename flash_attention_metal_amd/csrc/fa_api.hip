@@ -7,10 +7,6 @@
 
 #include "fa_common.h"
 
-#ifndef FA_PP_MIN_BLOCKS
-#define FA_PP_MIN_BLOCKS 1000000000  // provisional: AUTO keeps the 128-row kernel until the paired-block kernel is measured
-#endif
-
 namespace {
 thread_local char g_err[512] = "";
 
@@ -75,14 +71,16 @@ int fa_resolve_variant(int dtype, int D) {
   return FA_ERR_UNSUPPORTED;
 }
 
-// The paired-block kernel needs enough 256-row blocks to fill the chip; below that the 128-row kernel's
-// finer grid wins.
+// AUTO between the matrix-core kernels (interleaved A/B on MI355X): the paired-block kernel
+// (one wave per SIMD, 256-row workgroups) wins at head_dim 128 once the sequence is long (>= 4096) and the grid
+// gives every CU at least two workgroups; everywhere else -- all of head_dim 64 included -- the 128-row kernel
+// with three waves per SIMD is faster.
 int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal) {
   (void)is_causal;
   const int v = fa_resolve_variant(dtype, D);
   if (v != FA_VARIANT_MFMA) return v;
   const long long blocks256 = (long long)B * H * ((N + 255) / 256);
-  if (fa::pp_supported(dtype, D) && blocks256 >= FA_PP_MIN_BLOCKS) return FA_VARIANT_MFMA_PP;
+  if (D == 128 && N >= 4096 && blocks256 >= 512 && fa::pp_supported(dtype, D)) return FA_VARIANT_MFMA_PP;
   return FA_VARIANT_MFMA;
 }
 
@@ -176,7 +174,7 @@ int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse, 
     return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: causal needs Nk >= Nq (bottom-right alignment would leave empty rows)");
   if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: scale=%g must be > 0", (double)scale);
   if (!fa::mfma_supported(dtype, D))
-    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: needs the matrix-core kernel (f16/bf16/fp8, D=64|128), got dtype=%s D=%d",
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: needs the matrix-core kernel (f16/bf16: D=32|64|96|128|256; fp8: D=64|128|256), got dtype=%s D=%d",
                 fa_dtype_name(dtype), D);
   const int sm = dtype == FA_DTYPE_FP8_E4M3 ? 16 : 8;
   if (q_head_stride < (long long)Nq * D || kv_head_stride < (long long)Nk * D || (q_batch_stride % sm) || (q_head_stride % sm) ||

@@ -39,16 +39,21 @@
 
 namespace fa {
 
+// head dims: 32, 64, 96, 128, 256 (scope row f3). LDS rows keep a power-of-two pitch (head_dim 96 rows sit in
+// 256-byte slots) so the XOR swizzles stay inside a row; head_dim 256 needs the whole register file
+// (128 accumulators for O^T alone): one workgroup per CU there.
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
+__global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
-  constexpr int RB = D * 2;                 // row bytes
-  constexpr int CPR = D / 8;                // 16-byte chunks per row
+  constexpr int GRB16 = D * 2;              // row bytes of a 16-bit row in global memory
+  constexpr int RB = (D == 96) ? 256 : D * 2;  // LDS row pitch (bytes)
+  constexpr int CPR = D / 8;                // 16-byte chunks per row that hold data
+  constexpr int CPRL = RB / 16;             // 16-byte slots per LDS row (power of two)
   constexpr int KS = D / 16;                // k-steps of the QK^T product
   constexpr int DB = D / 32;                // 32-wide d blocks of O^T
-  constexpr int TILE = BN * RB;             // bytes of one K (or V) tile
+  constexpr int TILE = BN * RB;             // bytes of one K (or V) tile in LDS
   constexpr bool IS_FP8 = std::is_same<Tag, FP8>::value;  // Q,K,V are e4m3 in HBM, bf16 from LDS onwards
   constexpr int GB = IS_FP8 ? 1 : 2;        // bytes per element in HBM
   constexpr int GRB = D * GB;               // global row bytes
@@ -99,21 +104,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
       const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rq, (unsigned)qrow * GRB + (2 * ks + h) * 8, 0, 0);
       qf[ks] = __builtin_bit_cast(vec8, fp8x8_to_bf16(t));
     } else {
-      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + (2 * ks + h) * 16, 0, 0);
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * GRB16 + (2 * ks + h) * 16, 0, 0);
       qf[ks] = __builtin_bit_cast(vec8, t);
     }
   }
 
   // ---- per-lane LDS offsets
   // K: ds_read_b128 of row (32kb + r), chunk (2ks + h); swizzle depends on r only
-  const int kx = (D == 64) ? ((r >> 1) & 7) : (r & 15);
+  const int kx = (D == 32) ? ((r >> 2) & 3) : (D == 64) ? ((r >> 1) & 7) : (r & 15);
   int koff[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) koff[ks] = r * RB + (((2 * ks + h) ^ kx) << 4);
   // V: transposed read; 16-lane group g covers d columns 16(g&1).. of block db,
   // lane 4q+pp of the group addresses row (.. + 4h + q), columns 4pp..4pp+3
   const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
-  const int vx = (D == 64) ? (((vq >> 1) & 1) << 2) : (vq << 2);
+  const int vx = (D == 32) ? 0 : (D == 64) ? (((vq >> 1) & 1) << 2) : (vq << 2);
   int voff[DB];
 #pragma unroll
   for (int db = 0; db < DB; ++db)
@@ -129,8 +134,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
     const int c = tid + i * NTHREADS;
     const int row = c / GCPR, gch = c % GCPR;
     st_g[i] = row * GRB + gch * 16;
-    const int skx = (D == 64) ? ((row >> 1) & 7) : (row & 15);
-    const int svx = (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+    const int skx = (D == 32) ? ((row >> 2) & 3) : (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    const int svx = (D == 32) ? 0 : (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
     const int ch = IS_FP8 ? 2 * gch : gch;
     st_k[i] = row * RB + ((ch ^ skx) << 4);
     st_v[i] = row * RB + ((ch ^ svx) << 4);
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
       w[1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
       // 16-byte chunk index XOR (r & (CPR-1)) spreads the rows over the banks
       const int col_b = (32 * db + 8 * g4 + 4 * h) * 2;
-      const int ch = (col_b >> 4) ^ (r & (CPR - 1));
+      const int ch = (col_b >> 4) ^ (r & (CPRL - 1));
       lds_write_b64(Ot + r * RB + (ch << 4) + (col_b & 15), w);
     }
   }
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
   for (int it = 0; it < WM * CPR / 64; ++it) {
     const int idx = it * 64 + lane;
     const int row = idx / CPR, ch = idx % CPR;
-    const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPR - 1))) << 4));
+    const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPRL - 1))) << 4));
     if (qw0 + row < p.N)
       *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
   }
@@ -409,13 +414,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_kernel(Params p) {
 
 // ---------------------------------------------------------------------------
 bool mfma_supported(int dtype, int D) {
-  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_FP8_E4M3) && (D == 64 || D == 128);
+  if (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) return D == 32 || D == 64 || D == 96 || D == 128 || D == 256;
+  return dtype == FA_DTYPE_FP8_E4M3 && (D == 64 || D == 128 || D == 256);  // an fp8 row must fill whole 16-byte chunks per thread
 }
 
 template <typename Tag, int D, bool CAUSAL>
 static hipError_t launch_one(const Params &p, hipStream_t s) {
   const int nQ = (p.N + BM - 1) / BM;
-  const size_t smem = 4 * BN * D * 2;
+  const size_t smem = 4 * BN * ((D == 96) ? 256 : D * 2);
   auto kern = fwd_mfma_kernel<Tag, D, CAUSAL>;
   if (smem > 48 * 1024) {
     hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
@@ -434,8 +440,15 @@ static hipError_t launch_one(const Params &p, hipStream_t s) {
 
 template <typename Tag>
 static hipError_t launch_dt(const Params &p, hipStream_t s) {
-  if (p.D == 64) return p.is_causal ? launch_one<Tag, 64, true>(p, s) : launch_one<Tag, 64, false>(p, s);
-  return p.is_causal ? launch_one<Tag, 128, true>(p, s) : launch_one<Tag, 128, false>(p, s);
+  constexpr bool IS8 = std::is_same<Tag, FP8>::value;
+  switch (p.D) {
+    case 64: return p.is_causal ? launch_one<Tag, 64, true>(p, s) : launch_one<Tag, 64, false>(p, s);
+    case 128: return p.is_causal ? launch_one<Tag, 128, true>(p, s) : launch_one<Tag, 128, false>(p, s);
+    case 256: return p.is_causal ? launch_one<Tag, 256, true>(p, s) : launch_one<Tag, 256, false>(p, s);
+    case 32: if constexpr (!IS8) return p.is_causal ? launch_one<Tag, 32, true>(p, s) : launch_one<Tag, 32, false>(p, s); break;
+    case 96: if constexpr (!IS8) return p.is_causal ? launch_one<Tag, 96, true>(p, s) : launch_one<Tag, 96, false>(p, s); break;
+  }
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s) {

@@ -77,7 +77,8 @@ enum fa_status {
  *                (rows contiguous, row pitch D); 16-byte aligned, strides multiples of 8 elements (16 for fp8)
  *  lse           device pointer to B*H*N floats, contiguous [B,H,N]; may be NULL
  *  N             sequence length (queries == keys); any N >= 1
- *  D             head dim: 64 or 128 for FA_VARIANT_MFMA, <= 128 (multiple of 4) otherwise
+ *  D             head dim: 32, 64, 96, 128 or 256 for FA_VARIANT_MFMA (fp8 inputs: 64, 128, 256), 64 or 128 for
+ *                FA_VARIANT_MFMA_PP, <= 128 (multiple of 4) for the scalar variants
  *  scale         softmax scale (> 0); the reference passes 1/sqrt(D) (main.mm:13)
  *  dtype/variant enums above
  *  hip_stream    hipStream_t on the current device, or NULL
@@ -96,7 +97,7 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
  *   q, o  [B, Hq, Nq, D] with q_batch_stride / q_head_stride;  k, v  [B, Hkv, Nk, D] with kv strides
  *   query head h attends to key/value head h / (Hq / Hkv)   (Hq % Hkv == 0)
  *   causal is bottom-right aligned: key j is visible to query i iff j <= i + (Nk - Nq); needs Nk >= Nq
- *   lse [B, Hq, Nq]. Matrix-core kernel only (f16 / bf16 / fp8 inputs, D = 64 or 128).
+ *   lse [B, Hq, Nq]. Matrix-core kernel only (f16 / bf16: D = 32, 64, 96, 128, 256; fp8 inputs: D = 64, 128, 256).
  * With Hkv = Hq, Nk = Nq and equal strides this is exactly fa_fwd(..., FA_VARIANT_MFMA).
  */
 int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse,

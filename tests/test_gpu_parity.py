@@ -92,7 +92,7 @@ def test_scalar_variants_batched_ragged(fa, oracle_mod, variant, dtype):
 # --------------------------------------------------------------------------
 @pytest.mark.parametrize("variant", MFMA_VARIANTS)
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
 @pytest.mark.parametrize("causal", [False, True])
 def test_mfma_vs_oracle(fa, oracle_mod, dtype, D, causal, variant):
     need(fa, dtype, variant, D)
@@ -104,7 +104,7 @@ def test_mfma_vs_oracle(fa, oracle_mod, dtype, D, causal, variant):
 
 
 @pytest.mark.parametrize("variant", MFMA_VARIANTS)
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("causal", [False, True])
 def test_mfma_fp8_inputs_vs_oracle(fa, oracle_mod, D, causal, variant):
     need(fa, "fp8", variant, D)
@@ -249,10 +249,10 @@ def test_head_batch_addressing_bit_exact(fa, oracle_mod, dtype, variant):
 def test_randomized_shapes(fa, oracle_mod, variant):
     # seeded random (B, H, N, D, dtype, causal, scale): ragged N everywhere, both head dims, custom scales
     rng = np.random.default_rng(2024)
-    for _ in range(40):
+    for _ in range(60):
         B, H = int(rng.integers(1, 4)), int(rng.integers(1, 6))
         N = int(rng.choice([1, 2, 31, 33, 64, 96, 127, 128, 191, 257, 300, 449, 640]))
-        D = int(rng.choice([64, 128]))
+        D = int(rng.choice([32, 64, 96, 128, 256]))
         dtype = str(rng.choice(["f16", "bf16", "fp8"]))
         causal = bool(rng.integers(0, 2))
         scale = float(rng.choice([D ** -0.5, 0.05, 0.2]))
@@ -276,7 +276,8 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
     cases = [  # B, Hq, Hkv, Nq, Nk, D, causal
         (2, 8, 2, 200, 200, 64, True), (1, 8, 1, 130, 130, 64, False), (2, 4, 4, 64, 300, 64, True),
         (1, 6, 3, 1, 257, 64, True), (1, 4, 2, 100, 37, 64, False), (1, 8, 2, 129, 512, 128, True),
-        (1, 2, 1, 77, 77, 128, True), (1, 16, 4, 33, 1000, 64, True)]
+        (1, 2, 1, 77, 77, 128, True), (1, 16, 4, 33, 1000, 64, True), (1, 4, 2, 70, 150, 32, True),
+        (1, 4, 1, 65, 65, 96, False), (1, 2, 2, 40, 300, 256, True)]
     for (B, Hq, Hkv, Nq, Nk, D, causal) in cases:
         q = oracle_mod.round_to(oracle_mod.init_random(B * Hq * Nq * D, int(rng.integers(1, 1 << 20))).reshape(B, Hq, Nq, D), dtype)
         k = oracle_mod.round_to(oracle_mod.init_random(B * Hkv * Nk * D, int(rng.integers(1, 1 << 20))).reshape(B, Hkv, Nk, D), dtype)
