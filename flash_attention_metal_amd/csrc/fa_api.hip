@@ -32,6 +32,7 @@ const char *fa_variant_name(int v) {
     case FA_VARIANT_TILED_V2: return "tiled_v2";
     case FA_VARIANT_MFMA: return "mfma";
     case FA_VARIANT_MFMA_PP: return "mfma_pp";
+    case FA_VARIANT_MFMA_SPLITKV: return "mfma_splitkv";
     default: return "?";
   }
 }
@@ -62,6 +63,7 @@ int fa_supported(int dtype, int variant, int D) {
     case FA_VARIANT_TILED_V2: return fa::tiled_v2_supported(dtype, D);
     case FA_VARIANT_MFMA: return fa::mfma_supported(dtype, D);
     case FA_VARIANT_MFMA_PP: return fa::pp_supported(dtype, D);
+    case FA_VARIANT_MFMA_SPLITKV: return fa::splitkv_supported(dtype, D);
     default: return 0;
   }
 }
@@ -73,14 +75,18 @@ int fa_resolve_variant(int dtype, int D) {
 
 // AUTO between the matrix-core kernels (interleaved A/B on MI355X): the paired-block kernel
 // (one wave per SIMD, 256-row workgroups) wins at head_dim 128 once the sequence is long (>= 4096) and the grid
-// gives every CU at least two workgroups; everywhere else -- all of head_dim 64 included -- the 128-row kernel
-// with three waves per SIMD is faster.
+// gives every CU at least two workgroups; the split-KV kernel wins on grids far smaller than the chip; everywhere
+// else -- all of head_dim 64 at scale included -- the 128-row kernel with three waves per SIMD is fastest.
 int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal) {
   (void)is_causal;
   const int v = fa_resolve_variant(dtype, D);
   if (v != FA_VARIANT_MFMA) return v;
   const long long blocks256 = (long long)B * H * ((N + 255) / 256);
   if (D == 128 && N >= 4096 && blocks256 >= 512 && fa::pp_supported(dtype, D)) return FA_VARIANT_MFMA_PP;
+  // small grids: fewer 128-row workgroups than a quarter of the CUs (or half, when each would walk >= 32 tiles):
+  // split the keys of every 32-row block over the waves of a workgroup instead (config 2: 15.9 -> 10.6 us)
+  const long long blocks128 = (long long)B * H * ((N + 127) / 128);
+  if (fa::splitkv_supported(dtype, D) && N > 64 && (blocks128 <= 64 || (blocks128 <= 128 && N >= 2048))) return FA_VARIANT_MFMA_SPLITKV;
   return FA_VARIANT_MFMA;
 }
 
@@ -91,6 +97,7 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
   const char *c = is_causal ? "true" : "false";
   switch (v) {
     case FA_VARIANT_MFMA_PP: snprintf(name, sizeof(name), "fa::fwd_pp_kernel<%s, %d, %s>", tag, D, c); break;
+    case FA_VARIANT_MFMA_SPLITKV: snprintf(name, sizeof(name), "fa::fwd_splitkv_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA: snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_TILED_V2: snprintf(name, sizeof(name), "fa::tiled_v2_kernel"); break;
     default: name[0] = 0;
@@ -154,6 +161,7 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
     case FA_VARIANT_TILED: e = fa::launch_tiled(p, dtype, s); break;
     case FA_VARIANT_TILED_V2: e = fa::launch_tiled_v2(p, dtype, s); break;
     case FA_VARIANT_MFMA_PP: e = fa::launch_pp(p, dtype, s); break;
+    case FA_VARIANT_MFMA_SPLITKV: e = fa::launch_splitkv(p, dtype, s); break;
     default: e = fa::launch_mfma(p, dtype, s); break;
   }
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)

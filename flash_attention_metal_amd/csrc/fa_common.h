@@ -34,12 +34,15 @@ hipError_t launch_tiled(const Params &p, int dtype, hipStream_t s);
 hipError_t launch_tiled_v2(const Params &p, int dtype, hipStream_t s);
 hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s);
 hipError_t launch_pp(const Params &p, int dtype, hipStream_t s);
+hipError_t launch_splitkv(const Params &p, int dtype, hipStream_t s);
 
 bool naive_supported(int dtype, int D);
 bool tiled_supported(int dtype, int D);
 bool tiled_v2_supported(int dtype, int D);
 bool mfma_supported(int dtype, int D);
 bool pp_supported(int dtype, int D);
+bool splitkv_supported(int dtype, int D);
+int splitkv_waves(int D, int Nk);
 bool bwd_supported(int dtype, int D);
 hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
                       float *dq, float *dk, float *dv, float *ws, int B, int H, int N, int D, float scale,

@@ -54,8 +54,10 @@ enum fa_variant {
   FA_VARIANT_TILED = 2,  /* LDS-tiled scalar "V1"                  (kernels.metal:72-171)  */
   FA_VARIANT_TILED_V2 = 3, /* 128-bit loads, double-buffered K/V "V2" (kernels.metal:462-596) */
   FA_VARIANT_MFMA = 4,   /* matrix-core kernel "V3/V4"             (kernels.metal:177,600): 128 query rows per workgroup */
-  FA_VARIANT_MFMA_PP = 5 /* same operator, paired-block pipeline: 256 query rows per workgroup, each wave interleaves the
-                            softmax of one 32-row block with the matrix products of the other (large grids) */
+  FA_VARIANT_MFMA_PP = 5, /* same operator, paired-block pipeline: 256 query rows per workgroup, one wave per SIMD, both
+                            32-row blocks of a wave share every K/V fragment (head_dim 128, long sequences) */
+  FA_VARIANT_MFMA_SPLITKV = 6 /* same operator for small grids: one 32-row query block per workgroup, its keys split over
+                            2-8 waves and merged in LDS through the row LSE (short sequences / few heads) */
 };
 
 /* status codes (0 = success, negative = error; text via fa_last_error()) */

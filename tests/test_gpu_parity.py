@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 TOL_O = {"f32": 2e-5, "f16": 1.5e-3, "bf16": 6e-3}
 TOL_LSE = {"f32": 2e-5, "f16": 1e-4, "bf16": 1e-4}
 # the matrix-core kernels: 128-row workgroups ("mfma"), paired-block pipeline ("mfma_pp"); "auto" picks by grid size
-MFMA_VARIANTS = ["mfma", "mfma_pp"]
+MFMA_VARIANTS = ["mfma", "mfma_pp", "mfma_splitkv"]
 
 
 def need(fa, dtype, variant, D):
@@ -149,7 +149,7 @@ def test_causal_row0_is_v0_bit_exact(fa, oracle_mod, dtype, variant):
 
 
 @pytest.mark.parametrize("variant,dtype", [("mfma", "bf16"), ("mfma", "f16"), ("mfma_pp", "bf16"), ("mfma_pp", "f16"),
-                                           ("tiled_v2", "f32"), ("tiled", "f32"), ("naive", "f32")])
+                                           ("mfma_splitkv", "bf16"), ("mfma_splitkv", "f16"), ("tiled_v2", "f32"), ("tiled", "f32"), ("naive", "f32")])
 def test_mask_index_probe_exact(fa, oracle_mod, variant, dtype):
     # Q = 0 -> uniform softmax; V[j,0] = delta(j,t): causal O[i,0] = 1/(i+1) for i >= t, EXACTLY 0 left of it.
     # t straddles every tile / wave / block boundary of the kernels (32, 64, 128).
@@ -471,7 +471,7 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, varia
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_pp"])
+@pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_pp", "mfma_splitkv"])
 def test_config2_full(fa, oracle_mod, variant):  # seqlen=1024, D=64, B=1, H=8, fp16, non-causal
     # BASELINE configs[1] names the "V2-style tiled kernel": variant tiled_v2 (kernels.metal:462-596) runs it at
     # full size in fp16; the matrix-core kernels are checked on the same tensors
