@@ -59,12 +59,19 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
   constexpr int GRB = D * GB;               // global row bytes
   constexpr int GTILE = BN * GRB;           // global bytes of one K (or V) tile
   constexpr int NCH = BN * (GRB / 16) / NTHREADS;  // staged 16-byte global chunks per thread per tile
-  constexpr bool VPRE = (D == 64);          // prefetch V^T fragments under the QK^T MFMAs
+  constexpr bool VPRE = (D == 64) && !IS_FP8;  // prefetch V^T fragments under the QK^T MFMAs
+  // fp8 inputs: the score product runs on v_mfma_scale_f32_32x32x64_f8f6f4 (unit E8M0 scales: an exact e4m3 product
+  // at twice the bf16 rate, K = 64 per instruction). K stays e4m3 in LDS (rows of D bytes) and Q stays e4m3 in
+  // registers; V is widened to bf16 while it is staged, because P has to be bf16 for the PV product anyway.
+  constexpr int KRB = IS_FP8 ? D : RB;      // K row pitch in LDS (bytes)
+  constexpr int KTILE = BN * KRB;           // bytes of one K tile in LDS
+  constexpr int NS8 = IS_FP8 ? D / 64 : 1;  // fp8: 64-wide k-steps of the score product
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
-  lds_char *Kbuf = smem;             // [2][BN][RB], rows swizzled
-  lds_char *Vbuf = smem + 2 * TILE;  // [2][BN][RB], rows swizzled
+  lds_char *Kbuf = smem;              // [2][BN][KRB], rows swizzled
+  lds_char *Vbuf = smem + 2 * KTILE;  // [2][BN][RB], rows swizzled
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -97,13 +104,18 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
 
   // ---- Q fragments (B operand of K.Q^T): lane (r,h) holds Q[qrow][16ks+8h .. +7].
   // Rows >= N read as zero through the descriptor's range check.
-  vec8 qf[KS];
+  vec8 qf[IS_FP8 ? 1 : KS];
+  i32x8 qf8[NS8];  // fp8: k-step j holds Q[qrow][64j + 32h .. +31] (32 e4m3 values; any k order works as long as K uses the same)
+  if constexpr (IS_FP8) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if constexpr (IS_FP8) {
-      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rq, (unsigned)qrow * GRB + (2 * ks + h) * 8, 0, 0);
-      qf[ks] = __builtin_bit_cast(vec8, fp8x8_to_bf16(t));
-    } else {
+    for (int j = 0; j < NS8; ++j) {
+      const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * GRB + 64 * j + 32 * h, 0, 0);
+      const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * GRB + 64 * j + 32 * h + 16, 0, 0);
+      qf8[j] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
       const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * GRB16 + (2 * ks + h) * 16, 0, 0);
       qf[ks] = __builtin_bit_cast(vec8, t);
     }
@@ -115,6 +127,8 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
   int koff[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) koff[ks] = r * RB + (((2 * ks + h) ^ kx) << 4);
+  // fp8 K rows are D bytes: the row image equals a 16-bit row of head_dim D/2 (same swizzle family)
+  const int kx8 = (D == 64) ? ((r >> 2) & 3) : (D == 128) ? ((r >> 1) & 7) : (r & 15);
   // V: transposed read; 16-lane group g covers d columns 16(g&1).. of block db,
   // lane 4q+pp of the group addresses row (.. + 4h + q), columns 4pp..4pp+3
   const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
@@ -137,11 +151,14 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
     const int skx = (D == 32) ? ((row >> 2) & 3) : (D == 64) ? ((row >> 1) & 7) : (row & 15);
     const int svx = (D == 32) ? 0 : (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
     const int ch = IS_FP8 ? 2 * gch : gch;
-    st_k[i] = row * RB + ((ch ^ skx) << 4);
     st_v[i] = row * RB + ((ch ^ svx) << 4);
     if constexpr (IS_FP8) {
-      st_k1[i] = row * RB + (((ch + 1) ^ skx) << 4);
+      const int skx8 = (D == 64) ? ((row >> 2) & 3) : (D == 128) ? ((row >> 1) & 7) : (row & 15);
+      st_k[i] = row * KRB + ((gch ^ skx8) << 4);  // raw e4m3 chunk
+      st_k1[i] = 0;
       st_v1[i] = row * RB + (((ch + 1) ^ svx) << 4);
+    } else {
+      st_k[i] = row * RB + ((ch ^ skx) << 4);
     }
   }
 
@@ -160,13 +177,12 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
   auto stage_write = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      if constexpr (IS_FP8) {  // e4m3 -> bf16 is exact; 16 elements = two bf16 chunks
-        lds_write_b128(Kbuf + buf * TILE + st_k[i], fp8x8_to_bf16(u32x2{kst[i][0], kst[i][1]}));
-        lds_write_b128(Kbuf + buf * TILE + st_k1[i], fp8x8_to_bf16(u32x2{kst[i][2], kst[i][3]}));
+      if constexpr (IS_FP8) {  // K: raw e4m3; V: e4m3 -> bf16 is exact, 16 elements = two bf16 chunks
+        lds_write_b128(Kbuf + buf * KTILE + st_k[i], kst[i]);
         lds_write_b128(Vbuf + buf * TILE + st_v[i], fp8x8_to_bf16(u32x2{vst[i][0], vst[i][1]}));
         lds_write_b128(Vbuf + buf * TILE + st_v1[i], fp8x8_to_bf16(u32x2{vst[i][2], vst[i][3]}));
       } else {
-        lds_write_b128(Kbuf + buf * TILE + st_k[i], kst[i]);
+        lds_write_b128(Kbuf + buf * KTILE + st_k[i], kst[i]);
         lds_write_b128(Vbuf + buf * TILE + st_v[i], vst[i]);
       }
     }
@@ -188,8 +204,13 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
   // Retire the Q-fragment loads HERE: hipcc's waitcnt pass otherwise carries them into the
   // loop as "possibly pending" and drains vmcnt(0) in front of every tile's first MFMAs, i.e.
   // waits for the prefetch it has just issued (seen in the .s as vmcnt(3)..vmcnt(0)).
+  if constexpr (IS_FP8) {
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    for (int j = 0; j < NS8; ++j) asm volatile("" : "+v"(qf8[j]));
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+  }
   __syncthreads();
 
   // One KV tile; BUF (the LDS buffer holding tile t) is a compile-time constant so every
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
     // the tile is past this wave's last query row
     const bool wave_active = !CAUSAL || (kv0 <= qw0 + WM - 1 + coff);
     if (wave_active) {
-      const lds_char *Kt = Kbuf + buf * TILE;
+      const lds_char *Kt = Kbuf + buf * KTILE;
       const lds_char *Vt = Vbuf + buf * TILE;
       // ---- S^T = K.Q^T : s[kb][reg] = S[q = r][key = kv0 + 32kb + (reg&3) + 8(reg>>2) + 4h]
       // All K fragment reads are issued before the first MFMA, and (D = 64) the V^T
@@ -240,6 +261,21 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
               vhi[vkb][vst][vdb] = lds_read_tr16(vb + 8 * RB);
             }
             __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else if constexpr (IS_FP8) {
+        // e4m3 score product: one scaled MFMA per 32 x 32 block and 64 head-dim elements (unit scales: 2^0)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
+#pragma unroll
+          for (int j = 0; j < NS8; ++j) {
+            const lds_char *kr = Kt + (32 * kb + r) * KRB;
+            const u32x4 a = lds_read_b128(kr + (((4 * j + 2 * h) ^ kx8) << 4));
+            const u32x4 b = lds_read_b128(kr + (((4 * j + 2 * h + 1) ^ kx8) << 4));
+            const i32x8 kf8 = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+            s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf8, qf8[j], s[kb], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
           }
         }
       } else {
@@ -421,7 +457,8 @@ bool mfma_supported(int dtype, int D) {
 template <typename Tag, int D, bool CAUSAL>
 static hipError_t launch_one(const Params &p, hipStream_t s) {
   const int nQ = (p.N + BM - 1) / BM;
-  const size_t smem = 4 * BN * ((D == 96) ? 256 : D * 2);
+  const size_t vrow = (D == 96) ? 256 : D * 2;  // fp8: K tiles stay e4m3 (rows of D bytes), V tiles are widened to bf16
+  const size_t smem = 2 * BN * (std::is_same<Tag, FP8>::value ? (size_t)D : vrow) + 2 * BN * vrow;
   auto kern = fwd_mfma_kernel<Tag, D, CAUSAL>;
   if (smem > 48 * 1024) {
     hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
