@@ -351,7 +351,7 @@ static void run_high_occupancy(const Options &opt, std::ofstream &ext) {
 }
 
 // ---- BASELINE.json configurations, sharded by (batch, head) over `devices` GPUs --------------
-struct Config { const char *name; int B, H, N, D, dtype; bool causal; };
+struct Config { const char *name; int B, H, N, D, dtype; bool causal; int variant = FA_VARIANT_AUTO; };
 
 static void shard(int n, int world, int rank, int &lo, int &hi) {  // block distribution, first n%world get one extra
   const int q = n / world, r = n % world;
@@ -380,7 +380,7 @@ static Timing run_config_sharded(const Config &c, int devices, int warmup, int i
     HIP_CHECK(hipStreamSynchronize(s));
     ++ready;
     while (ready.load() < devices) std::this_thread::yield();  // start the timed launches together
-    per[dev] = time_forward(FA_VARIANT_AUTO, c.dtype, q, k, v, o, (float *)lse.p, 1, mine, c.N, c.D, c.causal, warmup, iters, s);
+    per[dev] = time_forward(c.variant, c.dtype, q, k, v, o, (float *)lse.p, 1, mine, c.N, c.D, c.causal, warmup, iters, s);
     (void)hipStreamDestroy(s);
   };
   std::vector<std::thread> th;
@@ -401,7 +401,9 @@ static void run_configs(const Options &opt, std::ofstream &ext) {
   std::cout << "\n--- BASELINE configurations (devices visible: " << ndev << ", used: " << G << ") ---\n";
   std::cout << "config,devices,B,H,N,D,dtype,causal,median(ms),TFLOPS,frac_of_MFMA_peak,frac_of_HBM_peak" << std::endl;
   const Config cfgs[] = {
-      {"c2", 1, 8, 1024, 64, FA_DTYPE_F16, false},
+      {"c2", 1, 8, 1024, 64, FA_DTYPE_F16, false},                          // "auto": the split-KV matrix-core kernel on this small grid
+      {"c2_v2", 1, 8, 1024, 64, FA_DTYPE_F16, false, FA_VARIANT_TILED_V2},  // the kernel BASELINE configs[1] names (kernels.metal:462-596)
+      {"c2_mfma", 1, 8, 1024, 64, FA_DTYPE_F16, false, FA_VARIANT_MFMA},    // the 128-row matrix-core kernel, for comparison
       {"c3", 4, 16, 4096, 64, FA_DTYPE_BF16, true},
       {"c4", 8, 32, 16384, 128, FA_DTYPE_BF16, true},  // 8-GPU config: on G GPUs, G/8 of its (b,h) slices
       {"c5", 4, 16, 8192, 64, FA_DTYPE_FP8_E4M3, true},  // fp8 in / fp32 accumulate / bf16 out (B,H assumed as c3)
@@ -409,6 +411,7 @@ static void run_configs(const Options &opt, std::ofstream &ext) {
   for (const Config &c0 : cfgs) {
     for (int g = 1; g <= G; g *= 2) {
       Config c = c0;
+      if (g > 1 && c.variant != FA_VARIANT_AUTO) continue;  // the named-variant rows are single-GPU comparisons
       if (std::string(c.name) == "c4") {  // weak scaling: 32 (b,h) slices per GPU, as on the 8-GPU node
         c.B = g;
       } else if (g > 1) {

@@ -5,6 +5,12 @@
 Lets the gfx950 kernel be called like any other torch operator (dispatcher, torch.compile graphs,
 fake-tensor shape propagation) and compared in-process with scaled_dot_product_attention. The op is
 registered for the CUDA/HIP device only -- there is deliberately no CPU implementation.
+
+Autograd: the op carries a backward formula that saves (q, k, v, o, lse) and calls fa_bwd()
+(csrc/fa_bwd_kernels.hip; the math of /root/reference/kernels.metal:905-1265, which consumes the
+forward's LSE). Shapes fa_bwd has no kernel for (head dims other than 64, fp8 / fp32 inputs,
+grouped heads, Nq != Nk) raise instead of returning a silent zero gradient; so does a gradient
+flowing into the LSE output.
 """
 from __future__ import annotations
 
@@ -12,7 +18,7 @@ from typing import Tuple
 
 import torch
 
-from .ops import flash_attention_forward
+from .ops import FaError, flash_attention_backward, flash_attention_forward, load_library
 
 _LIB = torch.library.Library("fa_mi355", "DEF")
 _LIB.define("attention_forward(Tensor q, Tensor k, Tensor v, bool is_causal=False, float scale=0.0) -> (Tensor, Tensor)")
@@ -31,6 +37,36 @@ def _meta(q, k, v, is_causal=False, scale=0.0):
 
 _LIB.impl("attention_forward", _impl, "CUDA")
 _LIB.impl("attention_forward", _meta, "Meta")
+
+
+def _setup_context(ctx, inputs, output):
+    q, k, v, is_causal, scale = inputs
+    o, lse = output
+    ctx.save_for_backward(q, k, v, o, lse)
+    ctx.is_causal, ctx.scale = bool(is_causal), float(scale)
+    ctx.set_materialize_grads(False)
+
+
+def _backward(ctx, grad_o, grad_lse):
+    q, k, v, o, lse = ctx.saved_tensors
+    if grad_lse is not None:
+        raise NotImplementedError("fa_mi355::attention_forward: no gradient through the LSE output")
+    if grad_o is None:
+        return None, None, None, None, None
+    B, H, N, D = q.shape
+    if q.shape != k.shape or q.dtype not in (torch.float16, torch.bfloat16) or \
+            not load_library().fa_bwd_supported({torch.float16: 1, torch.bfloat16: 2}[q.dtype], D):
+        raise FaError(-2, f"no backward kernel for q {tuple(q.shape)} k {tuple(k.shape)} {q.dtype} "
+                          "(fa_bwd: f16 / bf16, square multi-head attention, head_dim 64)")
+    go = grad_o.to(q.dtype)
+    if go.stride() != q.stride():
+        go = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device).copy_(go)
+    dq, dk, dv = flash_attention_backward(q, k, v, o, go, lse, is_causal=ctx.is_causal,
+                                          scale=(ctx.scale if ctx.scale > 0 else None))
+    return dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype), None, None
+
+
+torch.library.register_autograd("fa_mi355::attention_forward", _backward, setup_context=_setup_context, lib=_LIB)
 
 
 def attention_forward(q, k, v, is_causal: bool = False, scale: float = 0.0):

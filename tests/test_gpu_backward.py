@@ -112,3 +112,38 @@ def test_backward_errors(fa):
     with pytest.raises(fa.FaError) as e:
         fa.flash_attention_backward(x, x, x, x, x, lse)
     assert e.value.status == -2  # head_dim 128 backward not built: reported, not faked
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_torch_op_autograd_matches_sdpa(fa, oracle_mod, dtype, causal):
+    # fa_bwd is reachable from torch.autograd through the custom op. Gradients of a random linear
+    # functional of O, against scaled_dot_product_attention differentiated in fp64 on the same (rounded) inputs.
+    import torch
+    import torch.nn.functional as F
+
+    from flash_attention_metal_amd import torch_op  # noqa: F401  (registers the op and its autograd formula)
+    from util import make_qkv, to_dev
+
+    B, H, N, D = 2, 3, 200, 64
+    q, k, v = (to_dev(x, dtype).requires_grad_(True) for x in make_qkv(oracle_mod, B, H, N, D, dtype))
+    w = torch.randn(B, H, N, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    o, lse = torch.ops.fa_mi355.attention_forward(q, k, v, causal, 0.0)
+    (o.float() * w).sum().backward()
+    q64, k64, v64 = (x.detach().double().requires_grad_(True) for x in (q, k, v))
+    ref = F.scaled_dot_product_attention(q64, k64, v64, is_causal=causal)
+    (ref * w.double()).sum().backward()
+    tol = {"f16": 4e-3, "bf16": 2e-2}[dtype]
+    for g, g64, name in ((q.grad, q64.grad, "dq"), (k.grad, k64.grad, "dk"), (v.grad, v64.grad, "dv")):
+        assert g is not None and g.dtype == q.dtype
+        err = (g.double() - g64).abs().max().item()
+        assert err < tol * g64.abs().max().item(), (name, err, g64.abs().max().item())
+    # shapes without a backward kernel raise instead of handing back a silent zero gradient
+    q128 = torch.zeros(1, 1, 64, 128, dtype=torch.bfloat16, device="cuda", requires_grad=True)
+    o128, _ = torch.ops.fa_mi355.attention_forward(q128, q128.detach(), q128.detach(), False, 0.0)
+    with pytest.raises(Exception):
+        o128.float().sum().backward()
+    o2, lse2 = torch.ops.fa_mi355.attention_forward(q, k, v, causal, 0.0)
+    with pytest.raises(Exception):  # no gradient through the LSE output
+        lse2.sum().backward()
+    torch.cuda.synchronize()
