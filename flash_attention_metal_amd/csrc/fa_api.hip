@@ -225,7 +225,7 @@ int fa_bwd(const void *q, const void *k, const void *v, const void *o, const voi
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)
     return fail(FA_ERR_INVALID_ARG, "fa_bwd: tensors must be 16-byte aligned");
   if (!fa::bwd_supported(dtype, D))
-    return fail(FA_ERR_UNSUPPORTED, "fa_bwd: no kernel for dtype=%s D=%d (f16/bf16, D=64)", fa_dtype_name(dtype), D);
+    return fail(FA_ERR_UNSUPPORTED, "fa_bwd: no kernel for dtype=%s D=%d (f16/bf16, D=64|128)", fa_dtype_name(dtype), D);
   if ((double)N * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "fa_bwd: one head exceeds 4 GiB");
   if (batch_stride < 0) return fail(FA_ERR_INVALID_ARG, "fa_bwd: negative batch stride");
   if ((long long)B * H > 0x7fffffffLL / ((N + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "fa_bwd: grid too large");

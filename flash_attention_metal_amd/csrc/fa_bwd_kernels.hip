@@ -1,4 +1,4 @@
-// fa_bwd_kernels.hip -- backward of the operator on the CDNA4 matrix cores (head_dim 64).
+// fa_bwd_kernels.hip -- backward of the operator on the CDNA4 matrix cores (head_dim 64 and 128).
 //
 // Replaces /root/reference/kernels.metal:905-1265 (flash_attention_backward_kernel): same
 // math -- D_i = rowsum(dO o O) (:983-990), P = exp(S*scale - L_i) recomputed from the forward's
@@ -37,45 +37,50 @@ struct BwdParams {
   int is_causal;
 };
 
-constexpr int BD = 64;        // head dim handled here
-constexpr int BRB = BD * 2;   // row bytes
-constexpr int BCPR = BD / 8;  // 16-byte chunks per row
-constexpr int BKS = BD / 16;
-constexpr int BDB = BD / 32;
-constexpr int BTILE = BN * BRB;  // one 64-row tile image
 constexpr float LOG2E = 1.4426950408889634f;
 
-__device__ __forceinline__ int row_swz(int row) { return (row >> 1) & 7; }         // row-read image (ds_read_b128)
-__device__ __forceinline__ int tr_swz(int row) { return ((row >> 1) & 1) << 2; }   // transposed-read image
+// per-head-dim constants of the kernels below (the reference kernel is head_dim 64 only, kernels.metal:905-1265;
+// 128 is the same algorithm with twice the k-steps / output blocks and one workgroup per CU)
+#define FA_BWD_CONSTS(D)                                                                         \
+  constexpr int BD = (D);          /* head dim */                                                \
+  constexpr int BRB = BD * 2;      /* row bytes */                                               \
+  constexpr int BCPR = BD / 8;     /* 16-byte chunks per row */                                  \
+  constexpr int BKS = BD / 16;     /* k-steps over the head dim */                               \
+  constexpr int BDB = BD / 32;     /* 32-wide output blocks over the head dim */                 \
+  constexpr int BTILE = BN * BRB;  /* one 64-row tile image */                                   \
+  auto row_swz = [](int row) { return BD == 64 ? ((row >> 1) & 7) : (row & 15); };        /* row-read image (ds_read_b128) */ \
+  auto tr_swz = [](int row) { return BD == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }; /* transposed-read image */ \
+  (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)row_swz; (void)tr_swz
 
 // ---------------------------------------------------------------------------
-template <typename elem>
+template <typename elem, int D>
 __global__ __launch_bounds__(256) void bwd_delta_kernel(BwdParams p) {
-  // 8 lanes per row, 16 bytes each; 32 rows per block
+  // D/8 lanes per row, 16 bytes each; 256 / (D/8) rows per block
+  constexpr int LPR = D / 8, RPB = 256 / LPR;
   const int tid = threadIdx.x;
-  const long long row = (long long)blockIdx.x * 32 + (tid >> 3);
+  const long long row = (long long)blockIdx.x * RPB + (tid / LPR);
   const long long rows = (long long)p.B * p.H * p.N;
   float acc = 0.0f;
   if (row < rows) {
     const long long bh = row / p.N, i = row % p.N;
-    const long long off = (bh / p.H) * p.batch_stride + (bh % p.H) * p.head_stride + i * BD + (tid & 7) * 8;
+    const long long off = (bh / p.H) * p.batch_stride + (bh % p.H) * p.head_stride + i * D + (tid % LPR) * 8;
     typedef elem e8 __attribute__((ext_vector_type(8)));
     const e8 a = *reinterpret_cast<const e8 *>((const elem *)p.o + off);
     const e8 b = *reinterpret_cast<const e8 *>((const elem *)p.d_o + off);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
   }
-  acc += __shfl_xor(acc, 1);
-  acc += __shfl_xor(acc, 2);
-  acc += __shfl_xor(acc, 4);
-  if (row < rows && (tid & 7) == 0) p.delta[row] = acc;
+#pragma unroll
+  for (int sft = 1; sft < LPR; sft <<= 1) acc += __shfl_xor(acc, sft);
+  if (row < rows && (tid % LPR) == 0) p.delta[row] = acc;
 }
 
 // ---------------------------------------------------------------------------
 // dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
 // ---------------------------------------------------------------------------
-template <typename Tag, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, 2) void bwd_dq_kernel(BwdParams p) {
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(BwdParams p) {
+  FA_BWD_CONSTS(D);
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -229,8 +234,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void bwd_dq_kernel(BwdParams p) {
 // ---------------------------------------------------------------------------
 // dK, dV: workgroup = 128 keys, wave = 32 keys (key on the lane, queries in the registers)
 // ---------------------------------------------------------------------------
-template <typename Tag, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, 2) void bwd_dkdv_kernel(BwdParams p) {
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(BwdParams p) {
+  FA_BWD_CONSTS(D);
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -408,31 +414,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void bwd_dkdv_kernel(BwdParams p) {
 }
 
 // ---------------------------------------------------------------------------
-bool bwd_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D == BD; }
+bool bwd_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128); }
+
+template <typename Tag, int D, bool CAUSAL>
+static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
+  using elem = typename MT<Tag>::elem;
+  constexpr int BTILE = BN * D * 2;
+  const long long rows = (long long)p.B * p.H * p.N;
+  constexpr int RPB = 256 / (D / 8);
+  const int nB = (p.N + BM - 1) / BM;
+  const size_t smem_dq = 6 * BTILE, smem_kv = 8 * BTILE + 1024;
+  auto kq = bwd_dq_kernel<Tag, D, CAUSAL>;
+  auto kk = bwd_dkdv_kernel<Tag, D, CAUSAL>;
+  hipError_t e = set_dyn_lds_once((const void *)kk, (int)smem_kv);
+  if (e != hipSuccess) return e;
+  if (smem_dq > 48 * 1024) {
+    e = set_dyn_lds_once((const void *)kq, (int)smem_dq);
+    if (e != hipSuccess) return e;
+  }
+  (void)hipGetLastError();  // do not report an older sticky error as this launch's
+  hipLaunchKernelGGL((bwd_delta_kernel<elem, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(kq, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
+  hipLaunchKernelGGL(kk, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_kv, s, p);
+  return hipGetLastError();
+}
 
 template <typename Tag>
 static hipError_t launch_bwd_dt(const BwdParams &p, hipStream_t s) {
-  using elem = typename MT<Tag>::elem;
-  const long long rows = (long long)p.B * p.H * p.N;
-  hipLaunchKernelGGL((bwd_delta_kernel<elem>), dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, p);
-  const int nB = (p.N + BM - 1) / BM;
-  const size_t smem_dq = 6 * BTILE, smem_kv = 8 * BTILE + 1024;
-  if (p.is_causal) {
-    auto kq = bwd_dq_kernel<Tag, true>;
-    auto kk = bwd_dkdv_kernel<Tag, true>;
-    hipError_t e = hipFuncSetAttribute((const void *)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kq, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
-    hipLaunchKernelGGL(kk, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_kv, s, p);
-  } else {
-    auto kq = bwd_dq_kernel<Tag, false>;
-    auto kk = bwd_dkdv_kernel<Tag, false>;
-    hipError_t e = hipFuncSetAttribute((const void *)kk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kq, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
-    hipLaunchKernelGGL(kk, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_kv, s, p);
-  }
-  return hipGetLastError();
+  if (p.D == 64) return p.is_causal ? launch_bwd_one<Tag, 64, true>(p, s) : launch_bwd_one<Tag, 64, false>(p, s);
+  return p.is_causal ? launch_bwd_one<Tag, 128, true>(p, s) : launch_bwd_one<Tag, 128, false>(p, s);
 }
 
 hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
