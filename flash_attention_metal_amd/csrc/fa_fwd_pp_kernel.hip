@@ -117,6 +117,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
   for (int db = 0; db < DB; ++db)
     voff[db] = (4 * h + vq) * RB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
 
+  // absolute LDS addresses of this lane's fragment reads, opaque to hipcc (it cannot fold the link-time dynamic-LDS
+  // base and otherwise re-adds it per read)
+  const lds_char *kptr[KS], *vptr[DB];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kptr[ks] = Kbuf + koff[ks];
+    asm volatile("" : "+v"(kptr[ks]));
+  }
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    vptr[db] = Vbuf + voff[db];
+    asm volatile("" : "+v"(vptr[db]));
+  }
+
   // ---- staging map: thread -> NCH 16-byte global chunks of a tile
   int st_g[NCH], st_k[NCH], st_v[NCH], st_k1[IS_FP8 ? NCH : 1], st_v1[IS_FP8 ? NCH : 1];
 #pragma unroll
@@ -344,11 +358,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     constexpr int NF = HAS_QK ? 2 * KS : 0;  // fragments (kb, ks); each feeds 2 MFMAs (block A, block B)
     constexpr int NG = HAS_QK ? 2 * NF : 1;  // gap groups
     constexpr int NR = 2 * NROW;             // finish rows of both blocks, interleaved A, B, A, ...
-    const lds_char *Kt = Kbuf + kbuf * TILE;
     u32x4 kf[NF > 0 ? NF : 1];
     auto kread = [&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value;
-      kf[f] = lds_read_b128(Kt + (f / KS) * 32 * RB + koff[f % KS]);
+      kf[f] = lds_read_b128(kptr[f % KS] + kbuf * TILE + (f / KS) * 32 * RB);
     };
     if constexpr (HAS_QK) {
       static_for<0, (LA < NF ? LA : NF)>([&](auto fc) __attribute__((always_inline)) { kread(fc); });
@@ -389,7 +402,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     constexpr int NR = 2 * NROW;     // start rows of both blocks
     using X0 = std::integral_constant<int, 0>;
     using X1 = std::integral_constant<int, 1>;
-    const lds_char *Vt = Vbuf + vbuf * TILE;
     if constexpr (HAS_NEXT && MASK) {
       fence_scores();
       sm_mask(X0{}, tn);
@@ -399,7 +411,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     auto vread = [&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value;
       constexpr int kb = f / (2 * DB), st = (f / DB) % 2, db = f % DB;
-      const lds_char *vb = Vt + (32 * kb + 16 * st) * RB + voff[db];
+      const lds_char *vb = vptr[db] + vbuf * TILE + (32 * kb + 16 * st) * RB;
       const s16x4 lo = lds_read_tr16(vb), hi = lds_read_tr16(vb + 8 * RB);
       vf[f] = __builtin_bit_cast(u32x4, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
@@ -477,10 +489,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
   // ---- pipeline fill: scores of tile 0, then its start half (always masked, always "rare":
   // the first tile sets the reference)
   {
-    const lds_char *Kt = Kbuf;
     static_for<0, 2 * KS>([&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value, kb = f / KS, ks = f % KS;
-      const u32x4 kfr = lds_read_b128(Kt + kb * 32 * RB + koff[ks]);
+      const u32x4 kfr = lds_read_b128(kptr[ks] + kb * 32 * RB);
 #ifdef FA_PP_QVGPR
       if constexpr (ks == 0) { M::mfma_v0(s[0][kb], kfr, qv[0][ks]); M::mfma_v0(s[1][kb], kfr, qv[1][ks]); }
       else { M::mfma_v(s[0][kb], kfr, qv[0][ks]); M::mfma_v(s[1][kb], kfr, qv[1][ks]); }

@@ -138,6 +138,20 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
   for (int db = 0; db < DB; ++db)
     voff[db] = (4 * h + vq) * RB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
 
+  // Absolute LDS addresses of this lane's fragment reads, made opaque ONCE: the dynamic-LDS base is a link-time
+  // constant hipcc cannot fold, and with plain offsets it re-added it ("v_add_u32 x, 0, y") six times per tile.
+  const lds_char *kptr[KS], *vptr[DB];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kptr[ks] = Kbuf + koff[ks];
+    asm volatile("" : "+v"(kptr[ks]));
+  }
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    vptr[db] = Vbuf + voff[db];
+    asm volatile("" : "+v"(vptr[db]));
+  }
+
   // ---- staging: thread -> NCH 16-byte chunks of the K tile and of the V tile
   // (fp8: a 16-byte global chunk holds 16 elements = chunks 2c and 2c+1 of the bf16 row image in LDS,
   //  each swizzled on its own: st_k/st_v address chunk 2c, st_k1/st_v1 chunk 2c+1)
@@ -224,8 +238,8 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
     // the tile is past this wave's last query row
     const bool wave_active = !CAUSAL || (kv0 <= qw0 + WM - 1 + coff);
     if (wave_active) {
-      const lds_char *Kt = Kbuf + buf * KTILE;
-      const lds_char *Vt = Vbuf + buf * TILE;
+      const lds_char *Kt = Kbuf + buf * KTILE;  // (fp8 score path only)
+      (void)Kt;
       // ---- S^T = K.Q^T : s[kb][reg] = S[q = r][key = kv0 + 32kb + (reg&3) + 8(reg>>2) + 4h]
       // All K fragment reads are issued before the first MFMA, and (D = 64) the V^T
       // fragments of the PV product are streamed in between the MFMAs, two transposed
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
-            kf[kb][ks] = __builtin_bit_cast(vec8, lds_read_b128(Kt + kb * 32 * RB + koff[ks]));
+            kf[kb][ks] = __builtin_bit_cast(vec8, lds_read_b128(kptr[ks] + buf * KTILE + kb * 32 * RB));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
             for (int u = 0; u < PER; ++u) {
               const int m = (kb * KS + ks) * PER + u;
               const int vkb = m / (2 * DB), vst = (m / DB) % 2, vdb = m % DB;
-              const lds_char *vb = Vt + (32 * vkb + 16 * vst) * RB + voff[vdb];
+              const lds_char *vb = vptr[vdb] + buf * TILE + (32 * vkb + 16 * vst) * RB;
               vlo[vkb][vst][vdb] = lds_read_tr16(vb);
               vhi[vkb][vst][vdb] = lds_read_tr16(vb + 8 * RB);
             }
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
         // its use instead (profile before: 9 % of wave time stalled on LDS issue, 14 % MFMA/VALU co-execution)
         constexpr int NK = 2 * KS, LA = 2;
         vec8 kf[NK];
-        auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(Kt + (i / KS) * 32 * RB + koff[i % KS])); };
+        auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(kptr[i % KS] + buf * KTILE + (i / KS) * 32 * RB)); };
 #pragma unroll
         for (int i = 0; i < LA; ++i) kread(i);
         __builtin_amdgcn_sched_barrier(0);
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
         constexpr int NV = 2 * 2 * DB, LA = 2;
         s16x4 wlo[NV], whi[NV];
         auto vread = [&](int j) {
-          const lds_char *vb = Vt + (32 * (j / (2 * DB)) + 16 * ((j / DB) % 2)) * RB + voff[j % DB];
+          const lds_char *vb = vptr[j % DB] + buf * TILE + (32 * (j / (2 * DB)) + 16 * ((j / DB) % 2)) * RB;
           wlo[j] = lds_read_tr16(vb);           // keys +4h+0..3   (k elements 0..3)
           whi[j] = lds_read_tr16(vb + 8 * RB);  // keys +8+4h+0..3 (k elements 4..7)
         };
