@@ -130,7 +130,9 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: strides must be multiples of %d elements", stride_mult);
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: tensors must be 16-byte aligned");
-  if ((double)N * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)
+  // 32-bit byte offsets inside a head; the staging loops may address up to two 64-key tiles past its end (range-checked
+  // by the buffer descriptor, but the offset itself must not wrap)
+  if ((double)(N + 128) * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: one head exceeds 4 GiB");
   if ((long long)B * H > 0x7fffffffLL / ((N + 127) / 128))
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: grid too large");
