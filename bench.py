@@ -302,16 +302,19 @@ def sweep(fa, torch, dev):
         lse = torch.empty(1, bh, n, dtype=torch.float32, device=dev)
         for _ in range(5):
             fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
-        iters = 30 if n <= 4096 else 10
+        # same method as the headline: HIP events around blocks of 10 back-to-back launches (an event pair around
+        # every single launch adds a host-side gap of several microseconds, which dominated the short rows)
+        nblk, per = (6, 10) if n <= 4096 else (3, 4)
         evs = []
-        for _ in range(iters):
+        for _ in range(nblk):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+            for _ in range(per):
+                fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
             b.record()
             evs.append((a, b))
         torch.cuda.synchronize(dev)
-        ms = sorted(a.elapsed_time(b) for a, b in evs)[iters // 2]
+        ms = sorted(a.elapsed_time(b) / per for a, b in evs)[nblk // 2]
         tf = fa.algorithmic_flops(1, bh, n, D, True) / (ms * 1e-3) / 1e12
         rows.append({"seqlen": n, "ms": round(ms, 5), "tflops": round(tf, 2), "mfma_frac": round(tf / PEAK_TFLOPS_BF16, 4)})
     return rows
