@@ -1,0 +1,731 @@
+// EXPERIMENT (round 2), not built into libfa_mi355.so: the 128-row matrix-core kernel with a PERSIST template flag.
+// One workgroup per resident slot (3 per CU) walks the heaviest-first block list through per-XCD ticket counters
+// (Params::sched, 9 words, re-armed by the last workgroup out), prefetches the next block's first K/V tile under its
+// last tile and the next Q fragments under the epilogue. Also carries -DFA_STAMPS (s_memrealtime stamps into the LSE
+// buffer, read by tools/stamps.py). To build it: copy over flash_attention_metal_amd/csrc/fa_mfma_kernel.hip, add
+// `unsigned *sched = nullptr;` to Params in fa_common.h, and run tools/mkvariant.sh.
+// Result on config 3 / N=8192 / N=16384 causal: parity with the plain launch (-1 % / -0.5 % / +0.1 %,
+// profiles/r02/ab_persistent_parity.log) -- per-block overhead falls from 4.5 us to 2.7 us and slots stay 100 % resident
+// (plain: 91 %), but the tail (slot end times spread 7-8 % around their mean, XCDs finishing up to 6 % apart) eats it.
+// Pitfalls found on the way are in DESIGN.md 6.6. With cross-XCD stealing the final draws of all slots hit eight
+// counters in one cache line at once and the launch took 40 % longer (ab_persistent_stealing.log).
+// fa_mfma_kernel.hip -- the operator on the CDNA4 matrix cores.
+//
+// Replaces /root/reference/kernels.metal:600-883 (flash_attention_v4_half_kernel)
+// and :177-455 (flash_attention_simd_kernel): same math -- tiled QK^T ->
+// online softmax -> PV, causal predicate `key > query -> masked`
+// (kernels.metal:748), whole-tile skip (kernels.metal:682), L = m + ln(l)
+// (kernels.metal:862-864) -- nothing else is shared with it. fp32 accumulators
+// for S, O, m, l (the reference accumulates S and O in half).
+//
+// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head)):
+//   * each wave owns 32 query rows; its Q fragments stay in registers
+//   * K/V tiles of 64 keys are double-buffered in LDS: the next tile's
+//     128-bit buffer loads are issued before the current tile's arithmetic and
+//     written to the other buffer after it; one barrier per tile
+//   * S^T = K.Q^T with v_mfma_f32_32x32x16 ("swapped" product): the query index
+//     lands on the lane, the 32 key scores of a block in that lane's 16
+//     accumulator registers (+16 in lane^32), so row max / row sum are
+//     in-register reductions plus ONE v_permlane32_swap -- no LDS round trip
+//   * P^T feeds the PV product straight from those registers as the B operand
+//     (k order inside a step is the accumulator's row order; V^T is read from
+//     LDS in the same order with ds_read_b64_tr_b16, so V stays row-major)
+//   * O^T accumulates in 16*(D/32) registers; the O rescale is skipped when no
+//     row max in the wave moved (exact: alpha == 1)
+//   * K rows are XOR-swizzled in LDS for conflict-free ds_read_b128, V rows for
+//     conflict-free transposed reads
+//   * epilogue: O tile -> LDS -> whole 128-byte rows, 16 B per lane
+//   * grid: 1-D, heads dealt to XCDs (blocks b and b+8 share an L2) so one
+//     head's K/V stays in one L2; causal q-blocks heaviest first
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <map>
+#include <mutex>
+
+#include "fa_mfma_common.h"
+
+#ifndef FA_DEFER_THR
+#define FA_DEFER_THR 8.0f  // log2 units: P values are bounded by 2^8 between rescales (0 = rescale whenever a max moved)
+#endif
+#ifndef FA_PERSIST
+#define FA_PERSIST 1  // 0: never use the persistent form (A/B)
+#endif
+#ifndef FA_PRIO
+#define FA_PRIO 2  // wave priority: 2 = raised around the MFMA clusters (+0.4..0.9 % A/B), 1 = around the softmax (-1..-6 %), 0 = off
+#endif
+
+namespace fa {
+
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+// head dims: 32, 64, 96, 128, 256 (scope row f3). LDS rows keep a power-of-two pitch (head_dim 96 rows sit in
+// 256-byte slots) so the XOR swizzles stay inside a row; head_dim 256 needs the whole register file
+// (128 accumulators for O^T alone): one workgroup per CU there.
+// PERSIST: the grid is one workgroup per resident slot; each workgroup walks the heaviest-first block list through
+// per-XCD ticket counters (p.sched) and starts the next block's first K/V tile and Q fragments under the last tile of
+// the current one, so a block's load latency and the launch of a fresh workgroup are paid once per slot, not per block.
+template <typename Tag, int D, bool CAUSAL, bool PERSIST>
+__global__ __launch_bounds__(NTHREADS, (PERSIST ? 3 : D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
+  using M = MT<Tag>;
+  using vec8 = typename M::vec8;
+  using elem = typename M::elem;
+  constexpr int GRB16 = D * 2;              // row bytes of a 16-bit row in global memory
+  constexpr int RB = (D == 96) ? 256 : D * 2;  // LDS row pitch (bytes)
+  constexpr int CPR = D / 8;                // 16-byte chunks per row that hold data
+  constexpr int CPRL = RB / 16;             // 16-byte slots per LDS row (power of two)
+  constexpr int KS = D / 16;                // k-steps of the QK^T product
+  constexpr int DB = D / 32;                // 32-wide d blocks of O^T
+  constexpr int TILE = BN * RB;             // bytes of one K (or V) tile in LDS
+  constexpr bool IS_FP8 = std::is_same<Tag, FP8>::value;  // Q,K,V are e4m3 in HBM, bf16 from LDS onwards
+  constexpr int GB = IS_FP8 ? 1 : 2;        // bytes per element in HBM
+  constexpr int GRB = D * GB;               // global row bytes
+  constexpr int GTILE = BN * GRB;           // global bytes of one K (or V) tile
+  constexpr int NCH = BN * (GRB / 16) / NTHREADS;  // staged 16-byte global chunks per thread per tile
+  constexpr bool VPRE = (D == 64) && !IS_FP8;  // prefetch V^T fragments under the QK^T MFMAs
+  // fp8 inputs: the score product runs on v_mfma_scale_f32_32x32x64_f8f6f4 (unit E8M0 scales: an exact e4m3 product
+  // at twice the bf16 rate, K = 64 per instruction). K stays e4m3 in LDS (rows of D bytes) and Q stays e4m3 in
+  // registers; V is widened to bf16 while it is staged, because P has to be bf16 for the PV product anyway.
+  constexpr int KRB = IS_FP8 ? D : RB;      // K row pitch in LDS (bytes)
+  constexpr int KTILE = BN * KRB;           // bytes of one K tile in LDS
+  constexpr int NS8 = IS_FP8 ? D / 64 : 1;  // fp8: 64-wide k-steps of the score product
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+  extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+  lds_char *smem = (lds_char *)smem_generic;
+  lds_char *Kbuf = smem;              // [2][BN][KRB], rows swizzled
+  lds_char *Vbuf = smem + 2 * KTILE;  // [2][BN][RB], rows swizzled
+  // PERSIST: the epilogue's O tile has its own region (the K/V buffers already hold the next block's first tile)
+  lds_char *Obuf = PERSIST ? smem + 2 * KTILE + 2 * TILE : smem;
+  lds_char *ticket_slot = smem + 2 * KTILE + 2 * TILE + (BM / WM) * WM * RB;  // PERSIST: one word
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FA_STAMPS  // timing experiments only: the LSE buffer receives s_memtime stamps (wave 0, lane 0) instead of the LSE
+  int stamp_blk = 0;
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (tid == 0 && stamp_blk < (PERSIST ? 40 : 1)) {
+      const unsigned long long t = __builtin_amdgcn_s_memrealtime();  // 100 MHz, one clock for the whole chip
+      ((unsigned *)p.lse)[((blockIdx.x * (PERSIST ? 40 : 1)) + stamp_blk) * 8 + k] = (unsigned)t;
+    }
+  };
+#define FA_STAMP(k) stamp(k)
+  FA_STAMP(4);
+#else
+#define FA_STAMP(k)
+#endif
+  const int r = lane & 31;  // query within the wave / key row within a block
+  const int h = lane >> 5;  // lane half
+
+  // ---- block -> (batch*head, q block). blocks b and b+8 share an XCD's L2:
+  // deal heads to the 8 residues so a head's K/V stays in one L2.
+  const int nQ = (p.N + BM - 1) / BM;
+  const int BH = p.B * p.H;
+  // grouped-query heads: query head h reads key/value head h / (H / Hkv); Nk keys per head.
+  // Causal with Nq != Nk is bottom-right aligned: key j visible to query i iff j <= i + coff.
+  const int coff = p.Nk - p.N;
+  const unsigned head_bytes = (unsigned)p.N * GRB, kv_head_bytes = (unsigned)p.Nk * GRB;
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  auto open_block = [&](int id, int &bh_, int &q0_, int &nT_, long long &base_, rsrc_t &rq_, rsrc_t &rk_, rsrc_t &rv_)
+                        __attribute__((always_inline)) {
+    int qb_;
+    map_block<CAUSAL>(id, BH, nQ, bh_, qb_, p.head_group);
+    base_ = (long long)(bh_ / p.H) * p.batch_stride + (long long)(bh_ % p.H) * p.head_stride;
+    const long long base_kv = (long long)(bh_ / p.H) * p.kv_batch_stride + (long long)((bh_ % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
+    q0_ = qb_ * BM;
+    rq_ = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.q + base_ * GB), 0, head_bytes, 0x00020000);
+    rk_ = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.k + base_kv * GB), 0, kv_head_bytes, 0x00020000);
+    rv_ = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.v + base_kv * GB), 0, kv_head_bytes, 0x00020000);
+    const int kv_end = CAUSAL ? min(p.Nk, q0_ + BM + coff) : p.Nk;
+    nT_ = (kv_end + BN - 1) / BN;
+  };
+  int bh, q0, nT;
+  long long base;
+  rsrc_t rq, rk, rv;
+  open_block(blockIdx.x, bh, q0, nT, base, rq, rk, rv);
+  int qw0 = q0 + wave * WM;  // first query row of this wave
+  int qrow = qw0 + r;
+
+  // ---- Q fragments (B operand of K.Q^T): lane (r,h) holds Q[qrow][16ks+8h .. +7].
+  // Rows >= N read as zero through the descriptor's range check.
+  vec8 qf[IS_FP8 ? 1 : KS];
+  i32x8 qf8[NS8];  // fp8: k-step j holds Q[qrow][64j + 32h .. +31] (32 e4m3 values; any k order works as long as K uses the same)
+  auto load_q = [&](const rsrc_t &rq_, int qrow_) __attribute__((always_inline)) {
+    if constexpr (IS_FP8) {
+#pragma unroll
+      for (int j = 0; j < NS8; ++j) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rq_, (unsigned)qrow_ * GRB + 64 * j + 32 * h, 0, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rq_, (unsigned)qrow_ * GRB + 64 * j + 32 * h + 16, 0, 0);
+        qf8[j] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq_, (unsigned)qrow_ * GRB16 + (2 * ks + h) * 16, 0, 0);
+        qf[ks] = __builtin_bit_cast(vec8, t);
+      }
+    }
+  };
+  // Retire Q-fragment loads at a chosen point: hipcc's waitcnt pass otherwise carries them into the tile loop as
+  // "possibly pending" and drains vmcnt(0) in front of every tile's first MFMAs, i.e. waits for the prefetch it
+  // has just issued (seen in the .s as vmcnt(3)..vmcnt(0)).
+  auto pin_q = [&]() __attribute__((always_inline)) {
+    if constexpr (IS_FP8) {
+#pragma unroll
+      for (int j = 0; j < NS8; ++j) asm volatile("" : "+v"(qf8[j]));
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    }
+  };
+  load_q(rq, qrow);
+
+  // ---- per-lane LDS offsets
+  // K: ds_read_b128 of row (32kb + r), chunk (2ks + h); swizzle depends on r only
+  const int kx = (D == 32) ? ((r >> 2) & 3) : (D == 64) ? ((r >> 1) & 7) : (r & 15);
+  int koff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) koff[ks] = r * RB + (((2 * ks + h) ^ kx) << 4);
+  // fp8 K rows are D bytes: the row image equals a 16-bit row of head_dim D/2 (same swizzle family)
+  const int kx8 = (D == 64) ? ((r >> 2) & 3) : (D == 128) ? ((r >> 1) & 7) : (r & 15);
+  // V: transposed read; 16-lane group g covers d columns 16(g&1).. of block db,
+  // lane 4q+pp of the group addresses row (.. + 4h + q), columns 4pp..4pp+3
+  const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
+  const int vx = (D == 32) ? 0 : (D == 64) ? (((vq >> 1) & 1) << 2) : (vq << 2);
+  int voff[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+    voff[db] = (4 * h + vq) * RB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
+
+  // Absolute LDS addresses of this lane's fragment reads, made opaque ONCE: the dynamic-LDS base is a link-time
+  // constant hipcc cannot fold, and with plain offsets it re-added it ("v_add_u32 x, 0, y") six times per tile.
+  const lds_char *kptr[KS], *vptr[DB];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kptr[ks] = Kbuf + koff[ks];
+    asm volatile("" : "+v"(kptr[ks]));
+  }
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    vptr[db] = Vbuf + voff[db];
+    asm volatile("" : "+v"(vptr[db]));
+  }
+
+  // ---- staging: thread -> NCH 16-byte chunks of the K tile and of the V tile
+  // (fp8: a 16-byte global chunk holds 16 elements = chunks 2c and 2c+1 of the bf16 row image in LDS,
+  //  each swizzled on its own: st_k/st_v address chunk 2c, st_k1/st_v1 chunk 2c+1)
+  constexpr int GCPR = GRB / 16;  // global chunks per row
+  int st_g[NCH], st_k[NCH], st_v[NCH], st_k1[IS_FP8 ? NCH : 1], st_v1[IS_FP8 ? NCH : 1];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NTHREADS;
+    const int row = c / GCPR, gch = c % GCPR;
+    st_g[i] = row * GRB + gch * 16;
+    const int skx = (D == 32) ? ((row >> 2) & 3) : (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    const int svx = (D == 32) ? 0 : (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+    const int ch = IS_FP8 ? 2 * gch : gch;
+    st_v[i] = row * RB + ((ch ^ svx) << 4);
+    if constexpr (IS_FP8) {
+      const int skx8 = (D == 64) ? ((row >> 2) & 3) : (D == 128) ? ((row >> 1) & 7) : (row & 15);
+      st_k[i] = row * KRB + ((gch ^ skx8) << 4);  // raw e4m3 chunk
+      st_k1[i] = 0;
+      st_v1[i] = row * RB + (((ch + 1) ^ svx) << 4);
+    } else {
+      st_k[i] = row * RB + ((ch ^ skx) << 4);
+    }
+  }
+
+  u32x4 kst[NCH], vst[NCH];
+  auto stage_load = [&](const rsrc_t &rk_, const rsrc_t &rv_, int t) __attribute__((always_inline)) {
+    const unsigned g0 = (unsigned)t * GTILE;  // tile t starts at key t*BN
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk_, g0 + st_g[i], 0, 0);
+      vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv_, g0 + st_g[i], 0, 0);
+    }
+  };
+  auto stage_write = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if constexpr (IS_FP8) {  // K: raw e4m3; V: e4m3 -> bf16 is exact, 16 elements = two bf16 chunks
+        lds_write_b128(Kbuf + buf * KTILE + st_k[i], kst[i]);
+        lds_write_b128(Vbuf + buf * TILE + st_v[i], fp8x8_to_bf16(u32x2{vst[i][0], vst[i][1]}));
+        lds_write_b128(Vbuf + buf * TILE + st_v1[i], fp8x8_to_bf16(u32x2{vst[i][2], vst[i][3]}));
+      } else {
+        lds_write_b128(Kbuf + buf * KTILE + st_k[i], kst[i]);
+        lds_write_b128(Vbuf + buf * TILE + st_v[i], vst[i]);
+      }
+    }
+  };
+
+  f32x16 oacc[DB];
+  float m, mthr, l;  // reference max of the raw (unscaled) scores of this row (may lag the true max by < 2^THR);
+                     // m + threshold (a tile max above it forces a rescale); this lane half's share of the running sum
+  const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
+  const float thr_raw = FA_DEFER_THR / c2;         // the threshold in raw-score units
+
+  // PERSIST: the block after this one (known after tile 0 of the current block)
+  // (only its id is carried; descriptors are rebuilt where they are used -- scalar registers are the scarce resource)
+  int nb = 0;
+  bool has_next = false;
+  // The next block is drawn LATE -- under the fourth tile from the end (an even tile: nT is even), a few microseconds
+  // before it is needed. Drawn at the start of a block, a slot reserves its second block at time 0 and the first two
+  // rounds degenerate into a static round-robin of the heaviest-first list (slot loads 60..116 tiles on config 3).
+  int t_draw = 0;
+  // the drawn ticket lives in a register of its own for the whole kernel: as a tile-local value hipcc put it in a
+  // scratch register that the softmax rewrites, and guarded every such write with s_waitcnt vmcnt(0)
+  unsigned ticket = 0;
+  const int nblocks = nQ * BH;
+
+  stage_load(rk, rv, 0);
+  stage_write(0);
+  pin_q();
+  __syncthreads();
+
+  auto load_q_next = [&]() __attribute__((always_inline)) {
+    int bh_n, q0_n, nT_n;
+    long long base_n;
+    rsrc_t rq_n, rk_n, rv_n;
+    open_block(nb, bh_n, q0_n, nT_n, base_n, rq_n, rk_n, rv_n);
+    load_q(rq_n, q0_n + wave * WM + r);
+  };
+  // One KV tile; BUF (the LDS buffer holding tile t) is a compile-time constant so every
+  // LDS address is a per-lane base register plus an immediate.
+  auto tile = [&](auto bufc, const int t) {
+    constexpr int buf = decltype(bufc)::value;
+    const int kv0 = t * BN;
+    const bool draw = PERSIST && buf == 0 && t == t_draw;
+    // in flight under this tile's MFMAs: the next tile, or (PERSIST) the first tile of the next block
+    if (t + 1 < nT) stage_load(rk, rv, t + 1);
+    else if (PERSIST && has_next) {
+      int bh_n, q0_n, nT_n;
+      long long base_n;
+      rsrc_t rq_n, rk_n, rv_n;
+      open_block(nb, bh_n, q0_n, nT_n, base_n, rq_n, rk_n, rv_n);
+      stage_load(rk_n, rv_n, 0);
+    }
+    if (draw && tid == 0) {
+      // the counter's offset goes through a VGPR the compiler cannot see through: with a provably uniform address
+      // hipcc rewrites the add into a wave reduction whose result it needs at once (s_waitcnt right here)
+      unsigned off = (blockIdx.x & 7) * 4u;
+      asm volatile("" : "+v"(off));
+      ticket = atomicAdd((unsigned *)((char *)p.sched + off), 1u);
+    }
+
+    // whole-tile skip per wave (kernels.metal:682 with Br = 32): every key of
+    // the tile is past this wave's last query row
+    const bool wave_active = !CAUSAL || (kv0 <= qw0 + WM - 1 + coff);
+    if (wave_active) {
+      const lds_char *Kt = Kbuf + buf * KTILE;  // (fp8 score path only)
+      (void)Kt;
+      // ---- S^T = K.Q^T : s[kb][reg] = S[q = r][key = kv0 + 32kb + (reg&3) + 8(reg>>2) + 4h]
+      // All K fragment reads are issued before the first MFMA, and (D = 64) the V^T
+      // fragments of the PV product are streamed in between the MFMAs, two transposed
+      // reads per MFMA: they do not depend on the softmax, so PV finds its operands in
+      // registers instead of waiting on LDS per MFMA. sched_barrier pins that order.
+#if FA_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
+      f32x16 s[2];
+      s16x4 vlo[VPRE ? 2 : 1][2][DB], vhi[VPRE ? 2 : 1][2][DB];
+      if constexpr (VPRE) {
+        vec8 kf[2][KS];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            kf[kb][ks] = __builtin_bit_cast(vec8, lds_read_b128(kptr[ks] + buf * KTILE + kb * 32 * RB));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s[kb] = M::mfma(kf[kb][ks], qf[ks], s[kb]);
+            constexpr int PER = (2 * 2 * DB) / (2 * KS);  // V block reads per QK MFMA (1 at D=64)
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+              const int m = (kb * KS + ks) * PER + u;
+              const int vkb = m / (2 * DB), vst = (m / DB) % 2, vdb = m % DB;
+              const lds_char *vb = vptr[vdb] + buf * TILE + (32 * vkb + 16 * vst) * RB;
+              vlo[vkb][vst][vdb] = lds_read_tr16(vb);
+              vhi[vkb][vst][vdb] = lds_read_tr16(vb + 8 * RB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else if constexpr (IS_FP8) {
+        // e4m3 score product: one scaled MFMA per 32 x 32 block and 64 head-dim elements (unit scales: 2^0)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
+#pragma unroll
+          for (int j = 0; j < NS8; ++j) {
+            const lds_char *kr = Kt + (32 * kb + r) * KRB;
+            const u32x4 a = lds_read_b128(kr + (((4 * j + 2 * h) ^ kx8) << 4));
+            const u32x4 b = lds_read_b128(kr + (((4 * j + 2 * h + 1) ^ kx8) << 4));
+            const i32x8 kf8 = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+            s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf8, qf8[j], s[kb], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          }
+        }
+      } else {
+        // head_dim 128: 16 K fragments would cost 64 VGPRs if held live; read each one LA MFMAs ahead of
+        // its use instead (profile before: 9 % of wave time stalled on LDS issue, 14 % MFMA/VALU co-execution)
+        constexpr int NK = 2 * KS, LA = 2;
+        vec8 kf[NK];
+        auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(kptr[i % KS] + buf * KTILE + (i / KS) * 32 * RB)); };
+#pragma unroll
+        for (int i = 0; i < LA; ++i) kread(i);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 zero;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+          s[i / KS] = M::mfma(kf[i], qf[i % KS], (i % KS) == 0 ? zero : s[i / KS]);
+          if (i + LA < NK) kread(i + LA);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- mask (only on tiles that cross the diagonal or the end of the sequence)
+      const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk);
+      if (need_mask) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          // masked iff key > qrow (kernels.metal:748) or key >= N
+          int lim = p.Nk - 1 - kv0 - 32 * kb - 4 * h;
+          if (CAUSAL) lim = min(lim, qrow + coff - kv0 - 32 * kb - 4 * h);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int kpart = (i & 3) + 8 * (i >> 2);
+            s[kb][i] = (kpart > lim) ? -INFINITY : s[kb][i];
+          }
+        }
+      }
+#if FA_PRIO == 1
+      __builtin_amdgcn_s_setprio(1);
+#elif FA_PRIO == 2
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      // ---- online softmax, lane-local + one half swap
+      float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);  // -> v_max3_f32
+      {
+        float lo, hi;
+        half_pair(mx, lo, hi);
+        mx = fmaxf(lo, hi);
+      }
+      // deferred row max (T13): O and l are rescaled only when some row's tile max exceeds the running
+      // reference m by more than 2^THR (log2 domain); otherwise p = exp2(c.s - c.m) <= 2^THR with the
+      // stale m. m, l and O stay mutually consistent, so LSE = m.scale + ln(l) is exact either way.
+      // On random data a 32-row wave sees SOME row's max move in most tiles, so the exact form
+      // (rescale whenever a max moved) paid the 32-multiply O pass nearly every tile.
+      if (__builtin_amdgcn_ballot_w64(mx > mthr) != 0) {  // wave-uniform; first tile: mthr = -inf
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c2);
+        l *= alpha;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+        m = m_new;
+        mthr = m_new + thr_raw;
+      }
+      const float mc = m * c2;
+      float ls0 = 0.0f, ls1 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc));
+        s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mc));
+        ls0 += s[0][i];
+        ls1 += s[1][i];
+      }
+      l += ls0 + ls1;
+#if FA_PRIO == 1
+      __builtin_amdgcn_s_setprio(0);
+#elif FA_PRIO == 2
+      __builtin_amdgcn_s_setprio(1);
+#endif
+      // ---- O^T += V^T.P^T : per 16-key step, P fragment = 8 accumulator registers
+      if constexpr (VPRE) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            vec8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (elem)s[kb][8 * st + j];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+              const s16x8 v8 = __builtin_shufflevector(vlo[kb][st][db], vhi[kb][st][db], 0, 1, 2, 3, 4, 5, 6, 7);
+              oacc[db] = M::mfma(__builtin_bit_cast(vec8, v8), pf, oacc[db]);
+            }
+          }
+        }
+      } else {
+        // V^T fragments just in time, LA MFMAs ahead (step j = (kb, st, db))
+        constexpr int NV = 2 * 2 * DB, LA = 2;
+        s16x4 wlo[NV], whi[NV];
+        auto vread = [&](int j) {
+          const lds_char *vb = vptr[j % DB] + buf * TILE + (32 * (j / (2 * DB)) + 16 * ((j / DB) % 2)) * RB;
+          wlo[j] = lds_read_tr16(vb);           // keys +4h+0..3   (k elements 0..3)
+          whi[j] = lds_read_tr16(vb + 8 * RB);  // keys +8+4h+0..3 (k elements 4..7)
+        };
+        vec8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[kb][st][j] = (elem)s[kb][8 * st + j];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) vread(j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const s16x8 v8 = __builtin_shufflevector(wlo[j], whi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+          oacc[j % DB] = M::mfma(__builtin_bit_cast(vec8, v8), pf[j / (2 * DB)][(j / DB) % 2], oacc[j % DB]);
+          if (j + LA < NV) vread(j + LA);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    if (draw && tid == 0) {
+      // class-local block list: this workgroup's XCD residue x owns ids x, x+8, ...; the first gridDim.x/8 of them were
+      // taken by blockIdx, the rest are drawn from p.sched[x]. When the own list is exhausted (the tail of the launch),
+      // take from the other XCDs' lists: the XCDs do not run at the same speed (slot end times differ by 6 %).
+      const int x = blockIdx.x & 7, g8 = (int)(gridDim.x >> 3);
+      int cand = 8 * (g8 + (int)ticket) + x;
+      for (int i = 1; i < 8 && cand >= nblocks; ++i) {
+        const int c = (x + i) & 7;
+        cand = 8 * (g8 + (int)atomicAdd(p.sched + c, 1u)) + c;
+      }
+      *(lds_u32 *)ticket_slot = (unsigned)cand;
+    }
+    if (t + 1 < nT || (PERSIST && has_next)) stage_write(buf ^ 1);
+    __syncthreads();
+    if (draw) {
+      nb = (int)__builtin_amdgcn_readfirstlane(*(lds_u32 *)ticket_slot);
+      has_next = nb < nblocks;
+    }
+  };
+  for (;;) {
+    FA_STAMP(0);
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) oacc[db][i] = 0.0f;
+    m = -INFINITY;
+    mthr = -INFINITY;
+    l = 0.0f;
+    if constexpr (PERSIST) {
+      has_next = false;
+      t_draw = nT >= 4 ? nT - 4 : 0;
+    }
+    for (int t = 0; t < nT; t += 2) {
+      tile(std::integral_constant<int, 0>{}, t);
+      if (t == 0) FA_STAMP(1);
+      if (PERSIST || t + 1 < nT) tile(std::integral_constant<int, 1>{}, t + 1);  // PERSIST: nT is even (host checks)
+    }
+    FA_STAMP(2);
+
+    // PERSIST: the Q fragments have fed their last MFMA: fetch the next block's under the epilogue
+    if (PERSIST && has_next) load_q_next();
+    // ---- epilogue: normalise, LSE, O tile -> LDS -> coalesced 16-byte stores
+    {
+      float lo, hi;
+      half_pair(l, lo, hi);
+      l = lo + hi;
+    }
+    const float inv_l = 1.0f / l;
+
+    // PERSIST: keep the epilogue's addresses out of the block loop's invariants (hipcc hoists them and then spills
+    // them across the tile loop; the reloads are vector-memory ops that wait for the previous O store)
+    int lane_e = lane;
+    if constexpr (PERSIST) asm volatile("" : "+v"(lane_e));
+    const int r_e = lane_e & 31, h_e = lane_e >> 5;
+    lds_char *Ot = Obuf + wave * (WM * RB);  // this wave's [32][D] tile (inside the K buffers unless PERSIST)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        // registers 4g4..4g4+3 = d columns 32db + 8g4 + 4h + 0..3 of row r
+        elem e0 = (elem)(oacc[db][4 * g4 + 0] * inv_l), e1 = (elem)(oacc[db][4 * g4 + 1] * inv_l);
+        elem e2 = (elem)(oacc[db][4 * g4 + 2] * inv_l), e3 = (elem)(oacc[db][4 * g4 + 3] * inv_l);
+        u32x2 w;
+        w[0] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+        w[1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+        // 16-byte chunk index XOR (r & (CPR-1)) spreads the rows over the banks
+        const int col_b = (32 * db + 8 * g4 + 4 * h_e) * 2;
+        const int ch = (col_b >> 4) ^ (r_e & (CPRL - 1));
+        lds_write_b64(Ot + r_e * RB + (ch << 4) + (col_b & 15), w);
+      }
+    }
+    if constexpr (PERSIST) {
+      __builtin_amdgcn_wave_barrier();  // the tile is this wave's own: LDS program order is enough
+      // Retire the next block's Q loads HERE, ahead of the O stores (vmcnt retires in issue order: waiting after the
+      // stores would wait for their write acknowledgements too), and ahead of the exit test, so that every edge back
+      // to the loop header carries no pending Q load.
+      pin_q();
+    } else {
+      __syncthreads();
+    }
+    elem *Og = (elem *)p.o + base;
+#pragma unroll
+    for (int it = 0; it < WM * CPR / 64; ++it) {
+      const int idx = it * 64 + lane_e;
+      const int row = idx / CPR, ch = idx % CPR;
+      const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPRL - 1))) << 4));
+      if (qw0 + row < p.N)
+        *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
+    }
+#ifdef FA_STAMPS
+    if (tid == 0 && stamp_blk < (PERSIST ? 40 : 1)) ((unsigned *)p.lse)[((blockIdx.x * (PERSIST ? 40 : 1)) + stamp_blk) * 8 + 7] = (unsigned)nT;
+    FA_STAMP(3);
+    ++stamp_blk;
+#else
+    if (p.lse != nullptr && h == 0 && qrow < p.N)
+      p.lse[(long long)bh * p.N + qrow] = m * p.scale + logf(l);
+#endif
+    if constexpr (!PERSIST) {
+      break;
+    } else {
+      if (!has_next) break;
+      open_block(nb, bh, q0, nT, base, rq, rk, rv);
+      qw0 = q0 + wave * WM;
+      qrow = qw0 + r;
+    }
+  }
+  if constexpr (PERSIST) {
+    // the last workgroup out re-arms the counters for the next launch that uses this slot (every workgroup has made its
+    // one failing draw before it gets here)
+    if (tid == 0) {
+      const unsigned done = atomicAdd(p.sched + 8, 1u);
+      if (done == gridDim.x - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(p.sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+bool mfma_supported(int dtype, int D) {
+  if (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) return D == 32 || D == 64 || D == 96 || D == 128 || D == 256;
+  return dtype == FA_DTYPE_FP8_E4M3 && (D == 64 || D == 128 || D == 256);  // an fp8 row must fill whole 16-byte chunks per thread
+}
+
+// Ticket counters for the persistent form: a pool of slots per device, zeroed once; a launch takes the next slot and
+// its last workgroup leaves the slot zeroed again. Two launches only share a slot if FA_SCHED_SLOTS other launches were
+// issued in between, i.e. never while both are in flight.
+constexpr int FA_SCHED_SLOTS = 1024, FA_SCHED_WORDS = 16;
+static unsigned *sched_slot(hipStream_t s) {
+  static std::mutex mu;
+  static std::map<int, unsigned *> pools;
+  static unsigned next = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = pools.find(dev);
+  if (it == pools.end()) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;  // no allocation inside a capture
+    unsigned *pool = nullptr;
+    const size_t bytes = (size_t)FA_SCHED_SLOTS * FA_SCHED_WORDS * sizeof(unsigned);
+    if (hipMalloc((void **)&pool, bytes) != hipSuccess || hipMemset(pool, 0, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      pool = nullptr;
+    }
+    it = pools.emplace(dev, pool).first;
+  }
+  if (it->second == nullptr) return nullptr;
+  return it->second + (size_t)FA_SCHED_WORDS * (next++ % FA_SCHED_SLOTS);
+}
+
+// resident workgroups of a kernel on the current device (occupancy x CUs), cached
+static int resident_slots(const void *fn, int smem) {
+  static std::mutex mu;
+  static std::map<std::pair<const void *, int>, int> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = cache.find({fn, dev});
+  if (it != cache.end()) return it->second;
+  int occ = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, NTHREADS, smem) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    occ = 0;
+  }
+  const int slots = (occ * cus) & ~7;
+  cache[{fn, dev}] = slots;
+  return slots;
+}
+
+template <typename Tag, int D, bool CAUSAL>
+static hipError_t launch_one(const Params &p, hipStream_t s) {
+  const int nQ = (p.N + BM - 1) / BM;
+  const size_t vrow = (D == 96) ? 256 : D * 2;  // fp8: K tiles stay e4m3 (rows of D bytes), V tiles are widened to bf16
+  const size_t smem = 2 * BN * (std::is_same<Tag, FP8>::value ? (size_t)D : vrow) + 2 * BN * vrow;
+  Params pp = p;
+  pp.head_group = causal_head_group(p, D, std::is_same<Tag, FP8>::value ? 1 : 2);
+#ifdef FA_DEBUG_KNOBS  // scheduling experiments only: never compiled into the shipped library
+  static const int env_head_group = [] { const char *e = getenv("FA_HEAD_GROUP"); return e ? atoi(e) : -1; }();
+  if (env_head_group >= 0) pp.head_group = env_head_group;
+#endif
+  const int nblocks = nQ * p.B * p.H;
+  // persistent form: head_dim 64, whole 128-row blocks (so every block has an even tile count), square heads, and
+  // more blocks than resident slots
+  if constexpr (D == 64) {
+    if (FA_PERSIST && p.N == p.Nk && p.N % BM == 0 && nblocks % 8 == 0) {
+      auto kern = fwd_mfma_kernel<Tag, D, CAUSAL, true>;
+      const size_t smem_p = smem + (BM / WM) * WM * vrow + 16;
+      hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem_p);
+      if (e != hipSuccess) return e;
+      int slots = resident_slots((const void *)kern, (int)smem_p);
+#ifdef FA_DEBUG_KNOBS
+      static const int env_slots = [] { const char *e = getenv("FA_SLOTS"); return e ? atoi(e) : 0; }();
+      static bool said = false;
+      if (!said) { fprintf(stderr, "[fa] persistent: resident slots %d, env %d, nblocks %d\n", slots, env_slots, nblocks); said = true; }
+      if (env_slots > 0) slots = env_slots;
+#endif
+      if (slots >= 8 && nblocks >= 2 * slots && (pp.sched = sched_slot(s)) != nullptr) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(kern, dim3(slots), dim3(NTHREADS), smem_p, s, pp);
+        return hipGetLastError();
+      }
+    }
+  }
+  auto kern = fwd_mfma_kernel<Tag, D, CAUSAL, false>;
+  if (smem > 48 * 1024) {
+    hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  (void)hipGetLastError();  // do not report an older sticky error as this launch's
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NTHREADS), smem, s, pp);
+  return hipGetLastError();
+}
+
+template <typename Tag>
+static hipError_t launch_dt(const Params &p, hipStream_t s) {
+  constexpr bool IS8 = std::is_same<Tag, FP8>::value;
+  switch (p.D) {
+    case 64: return p.is_causal ? launch_one<Tag, 64, true>(p, s) : launch_one<Tag, 64, false>(p, s);
+    case 128: return p.is_causal ? launch_one<Tag, 128, true>(p, s) : launch_one<Tag, 128, false>(p, s);
+    case 256: return p.is_causal ? launch_one<Tag, 256, true>(p, s) : launch_one<Tag, 256, false>(p, s);
+    case 32: if constexpr (!IS8) return p.is_causal ? launch_one<Tag, 32, true>(p, s) : launch_one<Tag, 32, false>(p, s); break;
+    case 96: if constexpr (!IS8) return p.is_causal ? launch_one<Tag, 96, true>(p, s) : launch_one<Tag, 96, false>(p, s); break;
+  }
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_mfma(const Params &p, int dtype, hipStream_t s) {
+  if (dtype == FA_DTYPE_FP8_E4M3) return launch_dt<FP8>(p, s);
+  return dtype == FA_DTYPE_F16 ? launch_dt<F16>(p, s) : launch_dt<BF16>(p, s);
+}
+
+}  // namespace fa
