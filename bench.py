@@ -300,8 +300,13 @@ def sweep(fa, torch, dev):
         q, k, v = mk(), mk(), mk()
         o = torch.empty_like(q)
         lse = torch.empty(1, bh, n, dtype=torch.float32, device=dev)
-        for _ in range(5):
-            fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+        # per-row warm-up by time, like the headline: the short rows before this one leave the chip lightly loaded and
+        # the clocks take tens of milliseconds to come back (5 warm-up launches put the N=4096 row 3-5 % under `value`)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.06:
+            for _ in range(20 if n <= 4096 else 4):
+                fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+            torch.cuda.synchronize(dev)
         # same method as the headline: HIP events around blocks of 10 back-to-back launches (an event pair around
         # every single launch adds a host-side gap of several microseconds, which dominated the short rows)
         nblk, per = (6, 10) if n <= 4096 else (3, 4)
