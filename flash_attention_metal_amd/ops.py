@@ -101,11 +101,13 @@ def flash_attention_forward(
         scale = 1.0 / math.sqrt(D)
     if stream is None:
         stream = torch.cuda.current_stream(q.device).cuda_stream
-    with torch.cuda.device(q.device):
-        st = lib.fa_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
-                        lse.data_ptr() if lse is not None else None,
-                        B, H, N, D, float(scale), bs, hs, int(bool(is_causal)),
-                        fa_dtype, VARIANTS[variant], stream)
+    args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+            B, H, N, D, float(scale), bs, hs, int(bool(is_causal)), fa_dtype, VARIANTS[variant], stream)
+    if q.device.index == torch.cuda.current_device():  # the common case: no device switch (it costs microseconds,
+        st = lib.fa_fwd(*args)                         # as much as a short-sequence kernel runs)
+    else:
+        with torch.cuda.device(q.device):
+            st = lib.fa_fwd(*args)
     if st != 0:
         raise FaError(st, lib.fa_last_error().decode())
     return out, lse
