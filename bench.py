@@ -300,12 +300,15 @@ def sweep(fa, torch, dev):
         q, k, v = mk(), mk(), mk()
         o = torch.empty_like(q)
         lse = torch.empty(1, bh, n, dtype=torch.float32, device=dev)
+        # validated once, launched many times: below N = 1024 the Python-side checks of flash_attention_forward cost
+        # as much as the kernel runs and the row would measure the host
+        plan = fa.ForwardPlan(q, k, v, is_causal=True, out=o, lse=lse)
         # per-row warm-up by time, like the headline: the short rows before this one leave the chip lightly loaded and
         # the clocks take tens of milliseconds to come back (5 warm-up launches put the N=4096 row 3-5 % under `value`)
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.06:
             for _ in range(20 if n <= 4096 else 4):
-                fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+                plan.launch()
             torch.cuda.synchronize(dev)
         # same method as the headline: HIP events around blocks of 10 back-to-back launches (an event pair around
         # every single launch adds a host-side gap of several microseconds, which dominated the short rows)
@@ -315,7 +318,7 @@ def sweep(fa, torch, dev):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(per):
-                fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+                plan.launch()
             b.record()
             evs.append((a, b))
         torch.cuda.synchronize(dev)

@@ -13,6 +13,7 @@ from .ops import (  # noqa: F401
     DTYPES,
     VARIANTS,
     FaError,
+    ForwardPlan,
     algorithmic_bytes,
     algorithmic_flops,
     flash_attention_backward,

@@ -58,22 +58,8 @@ def _strides(t: torch.Tensor) -> Tuple[int, int]:
     return bs, hs
 
 
-def flash_attention_forward(
-    q: torch.Tensor,
-    k: torch.Tensor,
-    v: torch.Tensor,
-    is_causal: bool = False,
-    scale: Optional[float] = None,
-    variant: str = "auto",
-    return_lse: bool = True,
-    out: Optional[torch.Tensor] = None,
-    lse: Optional[torch.Tensor] = None,
-    stream: Optional[int] = None,
-) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
-    """Launch the gfx950 kernel on the current torch stream (asynchronous)."""
-    lib = load_library()
-    if q.dim() == 4 and k.dim() == 4 and k.shape == v.shape and q.shape != k.shape:
-        return _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream)  # GQA / Nq != Nk
+def _prepare_forward(q, k, v, is_causal, scale, variant, return_lse, out, lse):
+    """Validate one (Q,K,V,O,LSE) call and return (argument tuple of fa_fwd without the stream, out, lse)."""
     if q.dim() != 4 or q.shape != k.shape or q.shape != v.shape:
         raise ValueError(f"q, k, v must share one [B,H,N,D] shape, got {tuple(q.shape)} {tuple(k.shape)} {tuple(v.shape)}")
     if not (q.is_cuda and k.is_cuda and v.is_cuda):
@@ -99,18 +85,60 @@ def flash_attention_forward(
         raise ValueError("lse must be contiguous fp32 [B,H,N] on q's device")
     if scale is None:
         scale = 1.0 / math.sqrt(D)
-    if stream is None:
-        stream = torch.cuda.current_stream(q.device).cuda_stream
     args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
-            B, H, N, D, float(scale), bs, hs, int(bool(is_causal)), fa_dtype, VARIANTS[variant], stream)
-    if q.device.index == torch.cuda.current_device():  # the common case: no device switch (it costs microseconds,
-        st = lib.fa_fwd(*args)                         # as much as a short-sequence kernel runs)
+            B, H, N, D, float(scale), bs, hs, int(bool(is_causal)), fa_dtype, VARIANTS[variant])
+    return args, out, lse
+
+
+def _launch_forward(lib, args, device, stream):
+    if stream is None:
+        stream = torch.cuda.current_stream(device).cuda_stream
+    if device.index == torch.cuda.current_device():  # the common case: no device switch (it costs microseconds,
+        st = lib.fa_fwd(*args, stream)                # as much as a short-sequence kernel runs)
     else:
-        with torch.cuda.device(q.device):
-            st = lib.fa_fwd(*args)
+        with torch.cuda.device(device):
+            st = lib.fa_fwd(*args, stream)
     if st != 0:
         raise FaError(st, lib.fa_last_error().decode())
+
+
+def flash_attention_forward(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    is_causal: bool = False,
+    scale: Optional[float] = None,
+    variant: str = "auto",
+    return_lse: bool = True,
+    out: Optional[torch.Tensor] = None,
+    lse: Optional[torch.Tensor] = None,
+    stream: Optional[int] = None,
+) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Launch the gfx950 kernel on the current torch stream (asynchronous)."""
+    lib = load_library()
+    if q.dim() == 4 and k.dim() == 4 and k.shape == v.shape and q.shape != k.shape:
+        return _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream)  # GQA / Nq != Nk
+    args, out, lse = _prepare_forward(q, k, v, is_causal, scale, variant, return_lse, out, lse)
+    _launch_forward(lib, args, q.device, stream)
     return out, lse
+
+
+class ForwardPlan:
+    """One validated forward call on fixed tensors, launched many times: the argument table is checked and encoded
+    once (what the reference host does per dispatch, /root/reference/main.mm:821-852), ``launch()`` only issues
+    ``fa_fwd``. For launch-bound shapes -- short sequences, where the Python-side checks of
+    ``flash_attention_forward`` cost as much as the kernel runs -- and for replaying a step loop. The plan keeps the
+    tensors alive; it does not notice if they are resized or freed behind its back (``Tensor.set_`` / ``resize_``)."""
+
+    def __init__(self, q, k, v, is_causal=False, scale=None, variant="auto", return_lse=True, out=None, lse=None):
+        self._lib = load_library()
+        self._args, self.out, self.lse = _prepare_forward(q, k, v, is_causal, scale, variant, return_lse, out, lse)
+        self._keep = (q, k, v)
+        self._device = q.device
+
+    def launch(self, stream: Optional[int] = None) -> None:
+        """Issue the kernel on ``stream`` (default: the current torch stream of the tensors' device); asynchronous."""
+        _launch_forward(self._lib, self._args, self._device, stream)
 
 
 def _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream):

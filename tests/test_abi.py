@@ -116,6 +116,8 @@ def test_operator_refuses_cpu_tensors(fa):
     x = torch.zeros(1, 1, 128, 64, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="no CPU path"):
         fa.flash_attention_forward(x, x, x)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fa.ForwardPlan(x, x, x)
 
 
 def test_product_never_imports_the_oracle():

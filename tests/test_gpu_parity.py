@@ -382,6 +382,30 @@ def test_launch_is_graph_capturable(fa, oracle_mod):
     assert not torch.equal(o, ref[0])
 
 
+def test_forward_plan_matches_direct_call(fa, oracle_mod):
+    # ForwardPlan = the checks of flash_attention_forward once + bare launches: same bits, sees new data in the same
+    # tensors, and rejects what the direct call rejects
+    import torch
+
+    for dtype, causal, shape in (("bf16", True, (2, 3, 200, 64)), ("f16", False, (1, 8, 1024, 64)), ("bf16", True, (1, 2, 300, 128))):
+        q, k, v = (to_dev(x, dtype) for x in make_qkv(oracle_mod, *shape, dtype))
+        o_ref, lse_ref = fa.flash_attention_forward(q, k, v, is_causal=causal)
+        plan = fa.ForwardPlan(q, k, v, is_causal=causal)
+        for _ in range(3):
+            plan.launch()
+        torch.cuda.synchronize()
+        assert torch.equal(plan.out, o_ref) and torch.equal(plan.lse, lse_ref)
+        q.copy_(q.flip(2))
+        plan.launch()
+        o2, lse2 = fa.flash_attention_forward(q, k, v, is_causal=causal)
+        torch.cuda.synchronize()
+        assert torch.equal(plan.out, o2) and torch.equal(plan.lse, lse2) and not torch.equal(o2, o_ref)
+    with pytest.raises(ValueError):
+        fa.ForwardPlan(q, k, v, out=torch.empty(1, 2, 300, 64, dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(ValueError):
+        fa.ForwardPlan(q, k[:, :, :10], v[:, :, :10], is_causal=True)  # Nq != Nk goes through flash_attention_forward
+
+
 def test_torch_custom_op_matches_sdpa(fa, oracle_mod):
     # the kernel as a torch operator, compared in-process with torch's own attention
     import torch
