@@ -8,6 +8,22 @@
 namespace fa {
 
 // One launch of the operator (mirror of the binding table kernels.metal:600-613).
+// Exact unsigned division by a run-time constant (Granlund-Montgomery): q = (t + ((n - t) >> sh1)) >> sh2 with
+// t = mulhi(mul, n). The kernels map a block id to (batch, head, q block) with five divisions by launch constants; as
+// generic divisions they cost ~30 instructions each and sat in front of the first global load of every workgroup.
+struct FastDiv {
+  unsigned mul = 1, sh1 = 0, sh2 = 0;  // default: divide by 1
+};
+inline FastDiv make_fastdiv(unsigned d) {  // d >= 1
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;  // ceil(log2 d)
+  FastDiv f;
+  f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.sh1 = l < 1 ? l : 1u;
+  f.sh2 = l > 1 ? l - 1 : 0u;
+  return f;
+}
+
 struct Params {
   const void *q, *k, *v;
   void *o;
@@ -20,6 +36,9 @@ struct Params {
   int Nk = 0, Hkv = 0;                          // keys per head; key/value heads (H % Hkv == 0)
   long long kv_batch_stride = 0, kv_head_stride = 0;
   int head_group = 0;  // internal: causal blocks are issued heaviest-first within groups of this many heads (0 = all)
+  // internal, filled by the matrix-core launchers (set_block_divisors): divisors of the block id -> (batch, head, q block) map
+  int nq = 0, hg = 0;  // q blocks per head for this kernel's block height; effective head group (a divisor of B*H)
+  FastDiv fd_h, fd_gq, fd_nq, fd_hg, fd_per;  // by H, H/Hkv, nq, hg, hg*nq
 };
 
 // dtype tags

@@ -90,12 +90,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
   const int r = lane & 31;
   const int h = lane >> 5;
 
-  const int nQ = (p.N + PP_BM - 1) / PP_BM;
-  const int BH = p.B * p.H;
   int bh, qb;
-  map_block<CAUSAL>(blockIdx.x, BH, nQ, bh, qb, p.head_group);
-  const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
-  const long long base_kv = (long long)(bh / p.H) * p.kv_batch_stride + (long long)((bh % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
+  map_block<CAUSAL>(blockIdx.x, p, bh, qb);
+  long long base, base_kv;
+  head_bases(bh, p, base, base_kv);
   const int coff = p.Nk - p.N;  // bottom-right aligned causal mask for Nq != Nk
   const int q0 = qb * PP_BM;
   const int qw0 = q0 + wave * PP_WM;
@@ -643,6 +641,7 @@ static hipError_t launch_pp_one(const Params &p, hipStream_t s) {
   }
   Params pp = p;
   pp.head_group = causal_head_group(p, D, std::is_same<Tag, FP8>::value ? 1 : 2);
+  set_block_divisors(pp, nQ, pp.head_group);
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
   hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
   return hipGetLastError();

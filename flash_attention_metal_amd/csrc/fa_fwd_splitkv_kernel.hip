@@ -48,10 +48,11 @@ __global__ __launch_bounds__(512, 1) void fwd_splitkv_kernel(Params p) {
   lds_char *Kt = smem + wave * (2 * TILE);    // this wave's private K tile, V tile behind it
   lds_char *Vt = Kt + TILE;
 
-  const int nQ = (p.N + WM - 1) / WM;
-  const int bh = blockIdx.x / nQ, qb = CAUSAL ? (nQ - 1 - blockIdx.x % nQ) : blockIdx.x % nQ;  // causal: heavy blocks first
-  const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
-  const long long base_kv = (long long)(bh / p.H) * p.kv_batch_stride + (long long)((bh % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
+  const int nQ = p.nq;
+  const int bh = (int)fdiv(blockIdx.x, p.fd_nq), qrem = (int)blockIdx.x - bh * nQ;
+  const int qb = CAUSAL ? (nQ - 1 - qrem) : qrem;  // causal: heavy blocks first
+  long long base, base_kv;
+  head_bases(bh, p, base, base_kv);
   const int coff = p.Nk - p.N;
   const int q0 = qb * WM;
   const int qrow = q0 + r;
@@ -308,8 +309,10 @@ static hipError_t launch_splitkv_one(const Params &p, hipStream_t s) {
     hipError_t e = set_dyn_lds_once((const void *)kern, 160 * 1024);
     if (e != hipSuccess) return e;
   }
+  Params pp = p;
+  set_block_divisors(pp, nQ, 0);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(64 * S), smem, s, p);
+  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(64 * S), smem, s, pp);
   return hipGetLastError();
 }
 

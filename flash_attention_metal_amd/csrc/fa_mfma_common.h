@@ -226,27 +226,44 @@ __device__ __forceinline__ void half_pair(float x, float &lo, float &hi) {
 //    q block nQ-1 of every head, then nQ-2 of every head, ... . Heavy-first only within a
 //    group of heads left the last group's 64-tile blocks starting late: measured 28 % over
 //    the ideal at N=4096 (simulated makespan 122 vs 88 tile-times; this order: 98).
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv &f) {
+  const unsigned t = __umulhi(f.mul, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+// block id -> (bh = batch*H + head, q block). Divisors come precomputed in Params (set_block_divisors).
 template <bool CAUSAL>
-__device__ __forceinline__ void map_block(int id, int BH, int nQ, int &bh, int &qb, int HG = 0) {
+__device__ __forceinline__ void map_block(int id, const Params &p, int &bh, int &qb) {
+  const int BH = p.B * p.H, nQ = p.nq;
   if (CAUSAL) {
     // heaviest-first within groups of HG heads (HG = BH: across all heads). A group keeps HG/8
     // heads per XCD in flight, which bounds the K/V working set of that XCD's L2.
-    if (HG <= 0 || HG > BH || BH % HG != 0) HG = BH;
-    const int per = HG * nQ, g = id / per, rem = id - g * per;
-    qb = nQ - 1 - rem / HG;
-    bh = g * HG + rem % HG;  // HG % 8 == 0  =>  id % 8 == bh % 8: the head keeps its XCD residue
+    const int HG = p.hg;
+    const int g = (int)fdiv((unsigned)id, p.fd_per), rem = id - g * HG * nQ;
+    const int rq = (int)fdiv((unsigned)rem, p.fd_hg);
+    qb = nQ - 1 - rq;
+    bh = g * HG + (rem - rq * HG);  // HG % 8 == 0  =>  id % 8 == bh % 8: the head keeps its XCD residue
     return;
   }
-  const int full = (BH / 8) * 8;  // heads that can be dealt 8 at a time
+  const int full = BH & ~7;  // heads that can be dealt 8 at a time
   if (id < full * nQ) {
     const int xcd = id & 7, slot = id >> 3;
-    bh = (slot / nQ) * 8 + xcd;
-    qb = slot % nQ;
+    const int sq = (int)fdiv((unsigned)slot, p.fd_nq);
+    bh = sq * 8 + xcd;
+    qb = slot - sq * nQ;
   } else {
     const int rem = id - full * nQ;
-    bh = full + rem / nQ;
-    qb = rem % nQ;
+    const int sq = (int)fdiv((unsigned)rem, p.fd_nq);
+    bh = full + sq;
+    qb = rem - sq * nQ;
   }
+}
+
+// element offsets of head bh in Q/O and in K/V (grouped-query heads: query head h reads key/value head h / (H / Hkv))
+__device__ __forceinline__ void head_bases(int bh, const Params &p, long long &base, long long &base_kv) {
+  const int b = (int)fdiv((unsigned)bh, p.fd_h), h = bh - b * p.H;
+  base = (long long)b * p.batch_stride + (long long)h * p.head_stride;
+  base_kv = (long long)b * p.kv_batch_stride + (long long)fdiv((unsigned)h, p.fd_gq) * p.kv_head_stride;
 }
 
 // ---- host-side launch helpers shared by the matrix-core kernel files ---------------------------
@@ -279,6 +296,21 @@ inline int causal_head_group(const Params &p, int D, int elem_bytes) {
   int hg = 8 * per_xcd;
   while (hg < BH && (BH % hg) != 0) hg += 8;
   return (BH % 8 == 0 && hg < BH) ? hg : 0;
+}
+
+// Fill the divisors map_block / head_bases use: nq = q blocks per head at this kernel's block height, head_group as
+// returned by causal_head_group (0 or anything that does not divide B*H = one group).
+inline void set_block_divisors(Params &p, int nq, int head_group) {
+  const int BH = p.B * p.H;
+  int hg = head_group;
+  if (hg <= 0 || hg > BH || BH % hg != 0) hg = BH;
+  p.nq = nq;
+  p.hg = hg;
+  p.fd_h = make_fastdiv((unsigned)p.H);
+  p.fd_gq = make_fastdiv((unsigned)(p.H / p.Hkv));
+  p.fd_nq = make_fastdiv((unsigned)nq);
+  p.fd_hg = make_fastdiv((unsigned)hg);
+  p.fd_per = make_fastdiv((unsigned)hg * (unsigned)nq);
 }
 
 }  // namespace fa

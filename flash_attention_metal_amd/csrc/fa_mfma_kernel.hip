@@ -81,14 +81,12 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
 
   // ---- block -> (batch*head, q block). blocks b and b+8 share an XCD's L2:
   // deal heads to the 8 residues so a head's K/V stays in one L2.
-  const int nQ = (p.N + BM - 1) / BM;
-  const int BH = p.B * p.H;
   int bh, qb;
-  map_block<CAUSAL>(blockIdx.x, BH, nQ, bh, qb, p.head_group);
-  const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
+  map_block<CAUSAL>(blockIdx.x, p, bh, qb);
+  long long base, base_kv;
+  head_bases(bh, p, base, base_kv);
   // grouped-query heads: query head h reads key/value head h / (H / Hkv); Nk keys per head.
   // Causal with Nq != Nk is bottom-right aligned: key j visible to query i iff j <= i + coff.
-  const long long base_kv = (long long)(bh / p.H) * p.kv_batch_stride + (long long)((bh % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
   const int coff = p.Nk - p.N;
   const int q0 = qb * BM;
   const int qw0 = q0 + wave * WM;  // first query row of this wave
@@ -484,6 +482,7 @@ static hipError_t launch_one(const Params &p, hipStream_t s) {
   static const int env_head_group = [] { const char *e = getenv("FA_HEAD_GROUP"); return e ? atoi(e) : -1; }();
   if (env_head_group >= 0) pp.head_group = env_head_group;
 #endif
+  set_block_divisors(pp, nQ, pp.head_group);
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
   hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
   return hipGetLastError();
