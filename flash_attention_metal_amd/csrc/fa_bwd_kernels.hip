@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   const int r = lane & 31, h = lane >> 5;
   const int nQ = (p.N + BM - 1) / BM;
   int bh, qb;
-  map_block<CAUSAL>(blockIdx.x, p.B * p.H, nQ, bh, qb);
+  map_block_div<CAUSAL>(blockIdx.x, p.B * p.H, nQ, bh, qb);
   const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
   const int q0 = qb * BM, qw0 = q0 + wave * WM, qrow = qw0 + r;
 

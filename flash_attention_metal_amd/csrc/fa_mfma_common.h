@@ -259,6 +259,27 @@ __device__ __forceinline__ void map_block(int id, const Params &p, int &bh, int 
   }
 }
 
+// The same map with plain divisions (backward kernels: BwdParams carries no precomputed divisors; one global group)
+template <bool CAUSAL>
+__device__ __forceinline__ void map_block_div(int id, int BH, int nQ, int &bh, int &qb) {
+  if (CAUSAL) {
+    const int rq = id / BH;
+    qb = nQ - 1 - rq;
+    bh = id - rq * BH;
+    return;
+  }
+  const int full = BH & ~7;
+  if (id < full * nQ) {
+    const int xcd = id & 7, slot = id >> 3;
+    bh = (slot / nQ) * 8 + xcd;
+    qb = slot % nQ;
+  } else {
+    const int rem = id - full * nQ;
+    bh = full + rem / nQ;
+    qb = rem % nQ;
+  }
+}
+
 // element offsets of head bh in Q/O and in K/V (grouped-query heads: query head h reads key/value head h / (H / Hkv))
 __device__ __forceinline__ void head_bases(int bh, const Params &p, long long &base, long long &base_kv) {
   const int b = (int)fdiv((unsigned)bh, p.fd_h), h = bh - b * p.H;

@@ -33,6 +33,9 @@
 #ifndef FA_DEFER_THR
 #define FA_DEFER_THR 8.0f  // log2 units: P values are bounded by 2^8 between rescales (0 = rescale whenever a max moved)
 #endif
+#ifndef FA_SUMTRIG
+#define FA_SUMTRIG 1  // 1: the row sums decide whether the reference max is stale (no per-tile max); 0: per-tile max vs threshold
+#endif
 #ifndef FA_PRIO
 #define FA_PRIO 2  // wave priority: 2 = raised around the MFMA clusters (+0.4..0.9 % A/B), 1 = around the softmax (-1..-6 %), 0 = off
 #endif
@@ -43,7 +46,7 @@ namespace fa {
 // 256-byte slots) so the XOR swizzles stay inside a row; head_dim 256 needs the whole register file
 // (128 accumulators for O^T alone): one workgroup per CU there.
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
+__global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -225,6 +228,44 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
   }
   __syncthreads();
 
+  const float sum_thr = __builtin_exp2f(FA_DEFER_THR);
+  // cold path of the softmax: the scores of the current tile once more (plain product, no prefetching)
+  auto recompute_scores = [&](auto bufc, f32x16 (&s)[2], const int kv0, const bool need_mask) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
+      if constexpr (IS_FP8) {
+#pragma unroll
+        for (int j = 0; j < NS8; ++j) {
+          const lds_char *kr = Kbuf + buf * KTILE + (32 * kb + r) * KRB;
+          const u32x4 a = lds_read_b128(kr + (((4 * j + 2 * h) ^ kx8) << 4));
+          const u32x4 b = lds_read_b128(kr + (((4 * j + 2 * h + 1) ^ kx8) << 4));
+          const i32x8 kf8 = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+          s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf8, qf8[j], s[kb], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const vec8 kf = __builtin_bit_cast(vec8, lds_read_b128(kptr[ks] + buf * KTILE + kb * 32 * RB));
+          s[kb] = M::mfma(kf, qf[ks], s[kb]);
+        }
+      }
+    }
+    if (need_mask) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        int lim = p.Nk - 1 - kv0 - 32 * kb - 4 * h;
+        if (CAUSAL) lim = min(lim, qrow + coff - kv0 - 32 * kb - 4 * h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int kpart = (i & 3) + 8 * (i >> 2);
+          s[kb][i] = (kpart > lim) ? -INFINITY : s[kb][i];
+        }
+      }
+    }
+  };
   // One KV tile; BUF (the LDS buffer holding tile t) is a compile-time constant so every
   // LDS address is a per-lane base register plus an immediate.
   auto tile = [&](auto bufc, const int t) {
@@ -330,38 +371,65 @@ __global__ __launch_bounds__(NTHREADS, (D <= 128 ? 2 : 1)) void fwd_mfma_kernel(
       __builtin_amdgcn_s_setprio(0);
 #endif
       // ---- online softmax, lane-local + one half swap
-      float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-      for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);  // -> v_max3_f32
-      {
-        float lo, hi;
-        half_pair(mx, lo, hi);
-        mx = fmaxf(lo, hi);
-      }
-      // deferred row max (T13): O and l are rescaled only when some row's tile max exceeds the running
-      // reference m by more than 2^THR (log2 domain); otherwise p = exp2(c.s - c.m) <= 2^THR with the
-      // stale m. m, l and O stay mutually consistent, so LSE = m.scale + ln(l) is exact either way.
-      // On random data a 32-row wave sees SOME row's max move in most tiles, so the exact form
-      // (rescale whenever a max moved) paid the 32-multiply O pass nearly every tile.
-      if (__builtin_amdgcn_ballot_w64(mx > mthr) != 0) {  // wave-uniform; first tile: mthr = -inf
-        const float m_new = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c2);
-        l *= alpha;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
-        m = m_new;
-        mthr = m_new + thr_raw;
-      }
-      const float mc = m * c2;
+      const float mc_old = m * c2;
       float ls0 = 0.0f, ls1 = 0.0f;
+#if FA_SUMTRIG
+      // Deferred row max (T13) WITHOUT a per-tile max: P = exp2(c.s - c.m) is formed with the running reference m, and
+      // the row sums that are needed anyway tell whether m is stale: a lane whose 32 probabilities add up to more than
+      // 2^THR (or to +inf) has a score more than 2^THR above m at worst. Only then -- and on the first tile, where m is
+      // -inf -- the wave takes the exact path: recompute the scores (they were overwritten by P; K is still in LDS),
+      // take the row max, rescale O and l, form P again. Saves the 16 v_max3 + swap + compare of every tile
+      // (141 -> 122 VALU per 16 MFMAs at head_dim 64); m, l and O stay mutually consistent, LSE = m.scale + ln(l) is exact.
+      bool exact = (t == 0);
+      if (t != 0) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc));
-        s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mc));
-        ls0 += s[0][i];
-        ls1 += s[1][i];
+        for (int i = 0; i < 16; ++i) {
+          s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc_old));
+          s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mc_old));
+          ls0 += s[0][i];
+          ls1 += s[1][i];
+        }
+        exact = __builtin_amdgcn_ballot_w64(ls0 + ls1 > sum_thr) != 0;  // wave-uniform
+        if (exact) recompute_scores(bufc, s, kv0, need_mask);
+      }
+      if (exact) {
+#else
+      {
+#endif
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);  // -> v_max3_f32
+        {
+          float lo, hi;
+          half_pair(mx, lo, hi);
+          mx = fmaxf(lo, hi);
+        }
+        // deferred row max (T13): O and l are rescaled only when some row's tile max exceeds the running
+        // reference m by more than 2^THR (log2 domain); otherwise p = exp2(c.s - c.m) <= 2^THR with the
+        // stale m. m, l and O stay mutually consistent, so LSE = m.scale + ln(l) is exact either way.
+        // On random data a 32-row wave sees SOME row's max move in most tiles, so the exact form
+        // (rescale whenever a max moved) paid the 32-multiply O pass nearly every tile.
+        if (FA_SUMTRIG || __builtin_amdgcn_ballot_w64(mx > mthr) != 0) {  // wave-uniform; first tile: mthr = -inf
+          const float m_new = fmaxf(m, mx);
+          const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c2);
+          l *= alpha;
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+          m = m_new;
+          mthr = m_new + thr_raw;
+        }
+        const float mc = m * c2;
+        ls0 = 0.0f;
+        ls1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc));
+          s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mc));
+          ls0 += s[0][i];
+          ls1 += s[1][i];
+        }
       }
       l += ls0 + ls1;
 #if FA_PRIO == 1
