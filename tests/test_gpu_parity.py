@@ -207,6 +207,27 @@ def test_forced_rescale_branch(fa, oracle_mod, dtype, variant):
 
 
 @pytest.mark.parametrize("variant", MFMA_VARIANTS)
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_reference_max_overflow_path(fa, oracle_mod, dtype, D, variant):
+    # The 128-row kernel forms P with a stale reference max and lets the ROW SUMS say when that max is too old: a
+    # score so far above it that exp2 overflows to +inf in fp32 must send the wave down the exact path (scores
+    # recomputed from LDS, max, rescale). Spikes of every size -- below the 2^8 threshold, above it, past the fp32
+    # exponent range -- at tile starts, inside masked diagonal tiles, in the last (ragged) tile, on one row and on all rows.
+    need(fa, dtype, variant, D)
+    B, H, N = 1, 2, 600
+    q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype, seeds=(11, 12, 13))
+    qn = (q * q).sum(-1, keepdims=True)  # |q_i|^2: a key c*q_i/|q_i|^2 scores exactly c against row i
+    for (i, j, c) in ((40, 3, 30.0), (40, 70, 400.0), (41, 41, 900.0), (200, 130, 25.0), (333, 320, 2000.0),
+                      (599, 576, 700.0), (599, 598, 1500.0), (128, 128, 1200.0), (450, 64, 60.0), (450, 449, 3000.0)):
+        k[:, :, j] = oracle_mod.round_to(q[:, :, i] / qn[:, :, i] * c, dtype)
+    k[:, 1, 500] = oracle_mod.round_to(np.full(D, 6.0, np.float32), dtype)  # one key that lifts MANY rows at once
+    q[:, 1, 520:] = oracle_mod.round_to(np.abs(q[:, 1, 520:]) + 2.0, dtype)
+    for causal in (False, True):
+        check(fa, oracle_mod, q, k, v, dtype, causal, variant, tol_scale=2.0)
+
+
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
 def test_asymmetric_structure(fa, oracle_mod, variant):
     # catches K<->V swaps, transposed S, wrong-row V gathers that Q==K==V data cannot
     N, D = 256, 64
