@@ -228,6 +228,23 @@ def test_reference_max_overflow_path(fa, oracle_mod, dtype, D, variant):
 
 
 @pytest.mark.parametrize("variant", MFMA_VARIANTS)
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_reference_max_overflow_path_fp8(fa, oracle_mod, D, variant):
+    # the same through the e4m3 score product: a few keys at the top of the e4m3 range (448) against rows of ~2
+    need(fa, "fp8", variant, D)
+    B, H, N = 1, 2, 600
+    q, k, v = make_qkv(oracle_mod, B, H, N, D, "fp8", seeds=(11, 12, 13), amp=2.0)
+    for j, c in ((3, 16.0), (70, 64.0), (130, 448.0), (320, 208.0), (576, 448.0), (598, 320.0)):
+        k[:, :, j] = oracle_mod.round_to(np.sign(q[:, :, (j * 7) % N]) * c, "fp8")
+    for causal in (False, True):
+        o, lse = run_op(fa, q, k, v, "fp8", causal, variant)
+        o64, l64 = oracle_mod.attn_fwd_f64(q, k, v, causal)
+        assert np.isfinite(o).all() and np.isfinite(lse).all()
+        assert np.abs(o - o64).max() < TOL_O["bf16"] * 2.0, (D, causal, np.abs(o - o64).max())
+        assert (np.abs(lse - l64) / np.maximum(1.0, np.abs(l64))).max() < 2e-5, (D, causal)  # = the 1e-4 absolute bar at LSE ~ 5
+
+
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
 def test_asymmetric_structure(fa, oracle_mod, variant):
     # catches K<->V swaps, transposed S, wrong-row V gathers that Q==K==V data cannot
     N, D = 256, 64
