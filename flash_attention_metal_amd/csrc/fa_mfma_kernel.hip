@@ -355,7 +355,11 @@ __global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fw
       if (need_mask) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-          // masked iff key > qrow (kernels.metal:748) or key >= N
+          // masked iff key > qrow (kernels.metal:748) or key >= N. A 32 x 32 block whose every key is visible to every
+          // row of the wave needs no work (wave-uniform test: of the two blocks of a diagonal tile one is of this
+          // kind or entirely masked): key offsets inside the block span 0..31, the wave's rows qw0..qw0+31.
+          const int xw = min(p.Nk - 1 - kv0 - 32 * kb, CAUSAL ? qw0 + coff - kv0 - 32 * kb : 0x7fffffff);
+          if (xw >= 31) continue;
           int lim = p.Nk - 1 - kv0 - 32 * kb - 4 * h;
           if (CAUSAL) lim = min(lim, qrow + coff - kv0 - 32 * kb - 4 * h);
 #pragma unroll
