@@ -106,6 +106,15 @@ static Timing time_forward(int variant, int dtype, const DevBuf &q, const DevBuf
                            float *lse, int B, int H, int N, int D, bool causal, int warmup, int iters,
                            hipStream_t s = nullptr) {
   for (int i = 0; i < warmup; ++i) forward(variant, dtype, q, k, v, o, lse, B, H, N, D, causal, s);
+  // ... and by TIME: the clocks need ~0.1-0.3 s of load to settle; five launches of a 150 us kernel measure the ramp
+  // (round 1's bench.py did exactly that: 642 instead of 866 TFLOP/s)
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    do {
+      for (int i = 0; i < 8; ++i) forward(variant, dtype, q, k, v, o, lse, B, H, N, D, causal, s);
+      HIP_CHECK(hipStreamSynchronize(s));
+    } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.15);
+  }
   std::vector<hipEvent_t> ev(2 * iters);
   for (auto &e : ev) HIP_CHECK(hipEventCreate(&e));
   for (int i = 0; i < iters; ++i) {
