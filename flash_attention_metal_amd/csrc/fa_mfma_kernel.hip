@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fw
       // 2^THR (or to +inf) has a score more than 2^THR above m at worst. Only then -- and on the first tile, where m is
       // -inf -- the wave takes the exact path: recompute the scores (they were overwritten by P; K is still in LDS),
       // take the row max, rescale O and l, form P again. Saves the 16 v_max3 + swap + compare of every tile
-      // (141 -> 122 VALU per 16 MFMAs at head_dim 64); m, l and O stay mutually consistent, LSE = m.scale + ln(l) is exact.
+      // (141 -> 118 VALU per 16 MFMAs at head_dim 64); m, l and O stay mutually consistent, LSE = m.scale + ln(l) is exact.
       bool exact = (t == 0);
       if (t != 0) {
 #pragma unroll
