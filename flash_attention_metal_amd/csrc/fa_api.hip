@@ -33,6 +33,7 @@ const char *fa_variant_name(int v) {
     case FA_VARIANT_MFMA: return "mfma";
     case FA_VARIANT_MFMA_PP: return "mfma_pp";
     case FA_VARIANT_MFMA_SPLITKV: return "mfma_splitkv";
+    case FA_VARIANT_MFMA_SPLIT2: return "mfma_split2";
     default: return "?";
   }
 }
@@ -64,6 +65,7 @@ int fa_supported(int dtype, int variant, int D) {
     case FA_VARIANT_MFMA: return fa::mfma_supported(dtype, D);
     case FA_VARIANT_MFMA_PP: return fa::pp_supported(dtype, D);
     case FA_VARIANT_MFMA_SPLITKV: return fa::splitkv_supported(dtype, D);
+    case FA_VARIANT_MFMA_SPLIT2: return fa::mfma_split2_supported(dtype, D);
     default: return 0;
   }
 }
@@ -75,7 +77,8 @@ int fa_resolve_variant(int dtype, int D) {
 
 // AUTO between the matrix-core kernels (interleaved A/B on MI355X): the paired-block kernel
 // (one wave per SIMD, 256-row workgroups) wins at head_dim 128 once the sequence is long (>= 4096) and the grid
-// gives every CU at least two workgroups; the split-KV kernel wins on grids far smaller than the chip; everywhere
+// gives every CU at least two workgroups; the split-KV kernel wins on grids far smaller than the chip, the eight-wave
+// form of the 128-row kernel on grids up to one workgroup per CU; everywhere
 // else -- all of head_dim 64 at scale included -- the 128-row kernel with three waves per SIMD is fastest.
 int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal) {
   (void)is_causal;
@@ -86,7 +89,10 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   // small grids: fewer 128-row workgroups than a quarter of the CUs (or half, when each would walk >= 32 tiles):
   // split the keys of every 32-row block over the waves of a workgroup instead (config 2: 15.9 -> 10.6 us)
   const long long blocks128 = (long long)B * H * ((N + 127) / 128);
-  if (fa::splitkv_supported(dtype, D) && N > 64 && (blocks128 <= 64 || (blocks128 <= 128 && N >= 2048))) return FA_VARIANT_MFMA_SPLITKV;
+  if (fa::splitkv_supported(dtype, D) && N > 64 && blocks128 <= 64) return FA_VARIANT_MFMA_SPLITKV;
+  // up to one 128-row workgroup per CU: the block's tiles are the critical path -- eight waves, even / odd tiles
+  // (h=32, N=1024 causal: 16.1 -> 14.2 us; h=8, N=2048: 27.3 -> 22.0 us, split-KV 25.1)
+  if (fa::mfma_split2_supported(dtype, D) && N >= 512 && blocks128 <= 256) return FA_VARIANT_MFMA_SPLIT2;
   return FA_VARIANT_MFMA;
 }
 
@@ -98,6 +104,7 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
   switch (v) {
     case FA_VARIANT_MFMA_PP: snprintf(name, sizeof(name), "fa::fwd_pp_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_SPLITKV: snprintf(name, sizeof(name), "fa::fwd_splitkv_kernel<%s, %d, %s>", tag, D, c); break;
+    case FA_VARIANT_MFMA_SPLIT2: snprintf(name, sizeof(name), "fa::fwd_mfma_split2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA: snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_TILED_V2: snprintf(name, sizeof(name), "fa::tiled_v2_kernel"); break;
     default: name[0] = 0;
@@ -164,6 +171,7 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
     case FA_VARIANT_TILED_V2: e = fa::launch_tiled_v2(p, dtype, s); break;
     case FA_VARIANT_MFMA_PP: e = fa::launch_pp(p, dtype, s); break;
     case FA_VARIANT_MFMA_SPLITKV: e = fa::launch_splitkv(p, dtype, s); break;
+    case FA_VARIANT_MFMA_SPLIT2: e = fa::launch_mfma_split2(p, dtype, s); break;
     default: e = fa::launch_mfma(p, dtype, s); break;
   }
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)

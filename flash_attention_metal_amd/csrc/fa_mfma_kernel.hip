@@ -28,6 +28,8 @@
 //     head's K/V stays in one L2; causal q-blocks heaviest first
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "fa_mfma_common.h"
 
 #ifndef FA_DEFER_THR
@@ -45,8 +47,11 @@ namespace fa {
 // head dims: 32, 64, 96, 128, 256 (scope row f3). LDS rows keep a power-of-two pitch (head_dim 96 rows sit in
 // 256-byte slots) so the XOR swizzles stay inside a row; head_dim 256 needs the whole register file
 // (128 accumulators for O^T alone): one workgroup per CU there.
-template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
+// SPLIT = 2 ("split2" kernel, for grids that leave most of the chip idle): eight waves per workgroup, waves 0-3 and 4-7
+// take the even and the odd KV tiles of the same 128 query rows -- each half with its own K/V buffers, staging and
+// (m, l, O^T) -- and merge once through LDS by their reference maxima. Halves the sequential tile count of a block.
+template <typename Tag, int D, bool CAUSAL, int SPLIT>
+__device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -72,13 +77,16 @@ __global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fw
   typedef int i32x8 __attribute__((ext_vector_type(8)));
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
-  lds_char *smem = (lds_char *)smem_generic;
+  const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int sp = (SPLIT == 1) ? 0 : (wave_all >> 2);  // which KV split this wave works on
+  constexpr int GROUP_LDS = 2 * KTILE + 2 * TILE;     // K and V double buffers of one split
+  lds_char *smem = (lds_char *)smem_generic + sp * GROUP_LDS;
   lds_char *Kbuf = smem;              // [2][BN][KRB], rows swizzled
   lds_char *Vbuf = smem + 2 * KTILE;  // [2][BN][RB], rows swizzled
 
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x & (NTHREADS - 1);  // thread within its split's 4 waves (staging map)
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = wave_all & 3;                 // row group: query rows 32*wave .. +31 of the block
   const int r = lane & 31;  // query within the wave / key row within a block
   const int h = lane >> 5;  // lane half
 
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fw
   const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
   const float thr_raw = FA_DEFER_THR / c2;         // the threshold in raw-score units
 
-  stage_load(0);
+  stage_load(sp);  // this split's first tile (past the end of a short head: zeros through the descriptor, never used)
   stage_write(0);
   // Retire the Q-fragment loads HERE: hipcc's waitcnt pass otherwise carries them into the
   // loop as "possibly pending" and drains vmcnt(0) in front of every tile's first MFMAs, i.e.
@@ -271,11 +279,11 @@ __global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fw
   auto tile = [&](auto bufc, const int t) {
     constexpr int buf = decltype(bufc)::value;
     const int kv0 = t * BN;
-    if (t + 1 < nT) stage_load(t + 1);  // in flight under this tile's MFMAs
+    if (t + SPLIT < nT) stage_load(t + SPLIT);  // this split's next tile, in flight under this tile's MFMAs
 
     // whole-tile skip per wave (kernels.metal:682 with Br = 32): every key of
     // the tile is past this wave's last query row
-    const bool wave_active = !CAUSAL || (kv0 <= qw0 + WM - 1 + coff);
+    const bool wave_active = (SPLIT == 1 || t < nT) && (!CAUSAL || (kv0 <= qw0 + WM - 1 + coff));
     if (wave_active) {
       const lds_char *Kt = Kbuf + buf * KTILE;  // (fp8 score path only)
       (void)Kt;
@@ -384,8 +392,8 @@ __global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fw
       // -inf -- the wave takes the exact path: recompute the scores (they were overwritten by P; K is still in LDS),
       // take the row max, rescale O and l, form P again. Saves the 16 v_max3 + swap + compare of every tile
       // (141 -> 118 VALU per 16 MFMAs at head_dim 64); m, l and O stay mutually consistent, LSE = m.scale + ln(l) is exact.
-      bool exact = (t == 0);
-      if (t != 0) {
+      bool exact = (t == sp);  // this split's first tile
+      if (t != sp) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc_old));
@@ -485,51 +493,94 @@ __global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fw
         }
       }
     }
-    if (t + 1 < nT) stage_write(buf ^ 1);
+    if (t + SPLIT < nT) stage_write(buf ^ 1);
     __syncthreads();
   };
-  for (int t = 0; t < nT; t += 2) {
-    tile(std::integral_constant<int, 0>{}, t);
-    if (t + 1 < nT) tile(std::integral_constant<int, 1>{}, t + 1);
+  const int steps = (nT + SPLIT - 1) / SPLIT;  // every wave runs the same number of steps (one barrier each)
+  for (int j = 0; j < steps; j += 2) {
+    tile(std::integral_constant<int, 0>{}, j * SPLIT + sp);
+    if (j + 1 < steps) tile(std::integral_constant<int, 1>{}, (j + 1) * SPLIT + sp);
   }
 
-  // ---- epilogue: normalise, LSE, O tile -> LDS -> coalesced 16-byte stores
-  {
-    float lo, hi;
-    half_pair(l, lo, hi);
-    l = lo + hi;
+  if constexpr (SPLIT == 2) {
+    // ---- merge the two splits: waves 4-7 publish (O^T, m, l) lane by lane, waves 0-3 fold them into their own by the
+    // reference maxima (a split that saw no tile has m = -inf, l = 0: weight 0). The buffer sits behind the epilogue's
+    // O tiles; the K/V buffers are free (last step's barrier).
+    constexpr int NACC = 16 * DB;
+    float *mb = (float *)((lds_char *)smem_generic + (BM / WM) * WM * RB) + (size_t)wave * (NACC + 2) * 64 + lane;
+    if (sp == 1) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mb[(16 * db + i) * 64] = oacc[db][i];
+      mb[NACC * 64] = m;
+      mb[(NACC + 1) * 64] = l;
+    }
+    __syncthreads();
+    if (sp == 0) {
+      const float m1 = mb[NACC * 64], l1 = mb[(NACC + 1) * 64];
+      const float mm = fmaxf(m, m1);  // split 0 owns tile 0: m is finite
+      const float a0 = __builtin_amdgcn_exp2f((m - mm) * c2), a1 = __builtin_amdgcn_exp2f((m1 - mm) * c2);
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[db][i] = oacc[db][i] * a0 + mb[(16 * db + i) * 64] * a1;
+      l = l * a0 + l1 * a1;
+      m = mm;
+    }
   }
-  const float inv_l = 1.0f / l;
-  if (p.lse != nullptr && h == 0 && qrow < p.N)
-    p.lse[(long long)bh * p.N + qrow] = m * p.scale + logf(l);
 
-  lds_char *Ot = smem + wave * (WM * RB);  // this wave's [32][D] tile (inside the K buffers)
+  // ---- epilogue: normalise, LSE, O tile -> LDS -> coalesced 16-byte stores (split2: waves 0-3 only; the others keep
+  // the barrier company)
+  lds_char *Ot = (lds_char *)smem_generic + wave * (WM * RB);  // this wave's [32][D] tile (inside the K buffers)
+  if (sp == 0) {
+    {
+      float lo, hi;
+      half_pair(l, lo, hi);
+      l = lo + hi;
+    }
+    const float inv_l = 1.0f / l;
+    if (p.lse != nullptr && h == 0 && qrow < p.N)
+      p.lse[(long long)bh * p.N + qrow] = m * p.scale + logf(l);
 #pragma unroll
-  for (int db = 0; db < DB; ++db) {
+    for (int db = 0; db < DB; ++db) {
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      // registers 4g4..4g4+3 = d columns 32db + 8g4 + 4h + 0..3 of row r
-      elem e0 = (elem)(oacc[db][4 * g4 + 0] * inv_l), e1 = (elem)(oacc[db][4 * g4 + 1] * inv_l);
-      elem e2 = (elem)(oacc[db][4 * g4 + 2] * inv_l), e3 = (elem)(oacc[db][4 * g4 + 3] * inv_l);
-      u32x2 w;
-      w[0] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
-      w[1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
-      // 16-byte chunk index XOR (r & (CPR-1)) spreads the rows over the banks
-      const int col_b = (32 * db + 8 * g4 + 4 * h) * 2;
-      const int ch = (col_b >> 4) ^ (r & (CPRL - 1));
-      lds_write_b64(Ot + r * RB + (ch << 4) + (col_b & 15), w);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        // registers 4g4..4g4+3 = d columns 32db + 8g4 + 4h + 0..3 of row r
+        elem e0 = (elem)(oacc[db][4 * g4 + 0] * inv_l), e1 = (elem)(oacc[db][4 * g4 + 1] * inv_l);
+        elem e2 = (elem)(oacc[db][4 * g4 + 2] * inv_l), e3 = (elem)(oacc[db][4 * g4 + 3] * inv_l);
+        u32x2 w;
+        w[0] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+        w[1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+        // 16-byte chunk index XOR (r & (CPR-1)) spreads the rows over the banks
+        const int col_b = (32 * db + 8 * g4 + 4 * h) * 2;
+        const int ch = (col_b >> 4) ^ (r & (CPRL - 1));
+        lds_write_b64(Ot + r * RB + (ch << 4) + (col_b & 15), w);
+      }
     }
   }
   __syncthreads();
-  elem *Og = (elem *)p.o + base;
+  if (sp == 0) {
+    elem *Og = (elem *)p.o + base;
 #pragma unroll
-  for (int it = 0; it < WM * CPR / 64; ++it) {
-    const int idx = it * 64 + lane;
-    const int row = idx / CPR, ch = idx % CPR;
-    const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPRL - 1))) << 4));
-    if (qw0 + row < p.N)
-      *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
+    for (int it = 0; it < WM * CPR / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / CPR, ch = idx % CPR;
+      const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPRL - 1))) << 4));
+      if (qw0 + row < p.N)
+        *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
+    }
   }
+}
+
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
+  fwd_mfma_body<Tag, D, CAUSAL, 1>(p);
+}
+
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(2 * NTHREADS, 2) void fwd_mfma_split2_kernel(Params p) {
+  fwd_mfma_body<Tag, D, CAUSAL, 2>(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -558,6 +609,41 @@ static hipError_t launch_one(const Params &p, hipStream_t s) {
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
   hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
   return hipGetLastError();
+}
+
+template <typename Tag, int D, bool CAUSAL>
+static hipError_t launch_split2_one(const Params &p, hipStream_t s) {
+  const int nQ = (p.N + BM - 1) / BM;
+  const size_t vrow = D * 2;
+  const size_t group = 2 * BN * (std::is_same<Tag, FP8>::value ? (size_t)D : vrow) + 2 * BN * vrow;  // as launch_one
+  const size_t merge_end = (size_t)(BM / WM) * WM * vrow + (size_t)(BM / WM) * (16 * (D / 32) + 2) * 64 * 4;
+  const size_t smem = std::max(2 * group, merge_end);
+  auto kern = fwd_mfma_split2_kernel<Tag, D, CAUSAL>;
+  if (smem > 48 * 1024) {
+    hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  Params pp = p;
+  pp.head_group = 0;
+  set_block_divisors(pp, nQ, 0);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(2 * NTHREADS), smem, s, pp);
+  return hipGetLastError();
+}
+
+bool mfma_split2_supported(int dtype, int D) {
+  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_FP8_E4M3) && (D == 64 || D == 128);
+}
+
+hipError_t launch_mfma_split2(const Params &p, int dtype, hipStream_t s) {
+  auto go = [&](auto tag) -> hipError_t {
+    using Tag = decltype(tag);
+    if (p.D == 64) return p.is_causal ? launch_split2_one<Tag, 64, true>(p, s) : launch_split2_one<Tag, 64, false>(p, s);
+    if (p.D == 128) return p.is_causal ? launch_split2_one<Tag, 128, true>(p, s) : launch_split2_one<Tag, 128, false>(p, s);
+    return hipErrorInvalidValue;
+  };
+  if (dtype == FA_DTYPE_FP8_E4M3) return go(FP8{});
+  return dtype == FA_DTYPE_F16 ? go(F16{}) : go(BF16{});
 }
 
 template <typename Tag>

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FA_MI355_VERSION 200 /* major*10000 + minor*100 + patch */
+#define FA_MI355_VERSION 201 /* major*10000 + minor*100 + patch */
 
 /* element type of Q, K, V and O */
 enum fa_dtype {
@@ -56,8 +56,11 @@ enum fa_variant {
   FA_VARIANT_MFMA = 4,   /* matrix-core kernel "V3/V4"             (kernels.metal:177,600): 128 query rows per workgroup */
   FA_VARIANT_MFMA_PP = 5, /* same operator, paired-block pipeline: 256 query rows per workgroup, one wave per SIMD, both
                             32-row blocks of a wave share every K/V fragment (head_dim 128, long sequences) */
-  FA_VARIANT_MFMA_SPLITKV = 6 /* same operator for small grids: one 32-row query block per workgroup, its keys split over
+  FA_VARIANT_MFMA_SPLITKV = 6, /* same operator for small grids: one 32-row query block per workgroup, its keys split over
                             2-8 waves and merged in LDS through the row LSE (short sequences / few heads) */
+  FA_VARIANT_MFMA_SPLIT2 = 7 /* same operator for grids that fill part of the chip: the 128-row workgroup of MFMA with eight
+                            waves, waves 0-3 / 4-7 taking the even / odd KV tiles and merging once (halves the sequential
+                            tile count of a block; head_dim 64, 128) */
 };
 
 /* status codes (0 = success, negative = error; text via fa_last_error()) */
