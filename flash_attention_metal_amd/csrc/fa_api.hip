@@ -34,6 +34,7 @@ const char *fa_variant_name(int v) {
     case FA_VARIANT_MFMA_PP: return "mfma_pp";
     case FA_VARIANT_MFMA_SPLITKV: return "mfma_splitkv";
     case FA_VARIANT_MFMA_SPLIT2: return "mfma_split2";
+    case FA_VARIANT_MFMA_EXACT: return "mfma_exact";
     default: return "?";
   }
 }
@@ -66,6 +67,7 @@ int fa_supported(int dtype, int variant, int D) {
     case FA_VARIANT_MFMA_PP: return fa::pp_supported(dtype, D);
     case FA_VARIANT_MFMA_SPLITKV: return fa::splitkv_supported(dtype, D);
     case FA_VARIANT_MFMA_SPLIT2: return fa::mfma_split2_supported(dtype, D);
+    case FA_VARIANT_MFMA_EXACT: return fa::mfma_supported(dtype, D);
     default: return 0;
   }
 }
@@ -105,7 +107,10 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
     case FA_VARIANT_MFMA_PP: snprintf(name, sizeof(name), "fa::fwd_pp_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_SPLITKV: snprintf(name, sizeof(name), "fa::fwd_splitkv_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_SPLIT2: snprintf(name, sizeof(name), "fa::fwd_mfma_split2_kernel<%s, %d, %s>", tag, D, c); break;
-    case FA_VARIANT_MFMA: snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s>", tag, D, c); break;
+    case FA_VARIANT_MFMA:
+      snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s, %s>", tag, D, c,
+               (dtype != FA_DTYPE_FP8_E4M3 && D <= 128) ? "true" : "false");  // pre-scaled operand where it exists
+      break;
     case FA_VARIANT_TILED_V2: snprintf(name, sizeof(name), "fa::tiled_v2_kernel"); break;
     default: name[0] = 0;
   }
@@ -163,6 +168,7 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
   p.is_causal = is_causal ? 1 : 0;
   p.Nk = N; p.Hkv = H;
   p.kv_batch_stride = batch_stride; p.kv_head_stride = head_stride;
+  p.exact = (variant == FA_VARIANT_MFMA_EXACT);
   hipStream_t s = (hipStream_t)hip_stream;
   hipError_t e;
   switch (variant) {

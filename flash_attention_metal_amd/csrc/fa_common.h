@@ -35,6 +35,7 @@ struct Params {
   // generalised operator (fa_fwd_ex; fa_fwd sets Nk = N, Hkv = H, kv strides = q strides):
   int Nk = 0, Hkv = 0;                          // keys per head; key/value heads (H % Hkv == 0)
   long long kv_batch_stride = 0, kv_head_stride = 0;
+  int exact = 0;       // 128-row kernel: 1 = no pre-scaled query operand (variant mfma_exact)
   int head_group = 0;  // internal: causal blocks are issued heaviest-first within groups of this many heads (0 = all)
   // internal, filled by the matrix-core launchers (set_block_divisors): divisors of the block id -> (batch, head, q block) map
   int nq = 0, hg = 0;  // q blocks per head for this kernel's block height; effective head group (a divisor of B*H)

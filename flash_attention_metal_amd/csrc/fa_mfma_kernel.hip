@@ -38,11 +38,24 @@
 #ifndef FA_SUMTRIG
 #define FA_SUMTRIG 1  // 1: the row sums decide whether the reference max is stale (no per-tile max); 0: per-tile max vs threshold
 #endif
+#ifndef FA_PRESCALE
+#define FA_PRESCALE 1  // 1 (f16/bf16): Q~ = round(scale.log2e.Q) once per block and -m (log2 units) as the C operand of each score chain: P = exp2(S') with no FMA
+#endif
+#ifndef FA_VPRE_HALF
+#define FA_VPRE_HALF 1  // 1: only the first 32 keys' V^T fragments are prefetched under the QK^T MFMAs, the second half under the first half's PV MFMAs (-16 live registers)
+#endif
 #ifndef FA_PRIO
 #define FA_PRIO 2  // wave priority: 2 = raised around the MFMA clusters (+0.4..0.9 % A/B), 1 = around the softmax (-1..-6 %), 0 = off
 #endif
 
 namespace fa {
+
+// Which (dtype, head_dim) the pre-scaled query operand exists for: fp8 Q cannot carry the factor (3 mantissa bits), and
+// head_dim 256 has no 16 registers to spare for the row-constant tuple.
+template <typename Tag, int D>
+constexpr bool prescale_applies() {
+  return (FA_PRESCALE != 0) && !std::is_same<Tag, FP8>::value && D <= 128;
+}
 
 // head dims: 32, 64, 96, 128, 256 (scope row f3). LDS rows keep a power-of-two pitch (head_dim 96 rows sit in
 // 256-byte slots) so the XOR swizzles stay inside a row; head_dim 256 needs the whole register file
@@ -50,7 +63,8 @@ namespace fa {
 // SPLIT = 2 ("split2" kernel, for grids that leave most of the chip idle): eight waves per workgroup, waves 0-3 and 4-7
 // take the even and the odd KV tiles of the same 128 query rows -- each half with its own K/V buffers, staging and
 // (m, l, O^T) -- and merge once through LDS by their reference maxima. Halves the sequential tile count of a block.
-template <typename Tag, int D, bool CAUSAL, int SPLIT>
+// PRESC: the pre-scaled query operand (see PRE below); false = every score scaled in fp32 (variant mfma_exact).
+template <typename Tag, int D, bool CAUSAL, int SPLIT, bool PRESC>
 __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
@@ -68,6 +82,13 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   constexpr int GTILE = BN * GRB;           // global bytes of one K (or V) tile
   constexpr int NCH = BN * (GRB / 16) / NTHREADS;  // staged 16-byte global chunks per thread per tile
   constexpr bool VPRE = (D == 64) && !IS_FP8;  // prefetch V^T fragments under the QK^T MFMAs
+  // Pre-scaled operand (f16/bf16): the Q fragments are multiplied by c = scale.log2(e) and rounded back to the input
+  // type ONCE per block, and the running reference -m (log2 units) is the C operand of the first MFMA of every score
+  // chain, so the matrix core hands out S' = c.q.k - m and P = exp2(S') needs no v_fma (kernels.metal:763-771 scales
+  // and subtracts per score). Costs one rounding of c.q (2^-9 relative for bf16, 2^-12 for f16) per operand element:
+  // the score error stays a fraction of the P rounding that follows; LSE error scales with the score magnitude
+  // (include/fa_mi355.h states the bound).
+  constexpr bool PRE = PRESC && prescale_applies<Tag, D>();
   // fp8 inputs: the score product runs on v_mfma_scale_f32_32x32x64_f8f6f4 (unit E8M0 scales: an exact e4m3 product
   // at twice the bf16 rate, K = 64 per instruction). K stays e4m3 in LDS (rows of D bytes) and Q stays e4m3 in
   // registers; V is widened to bf16 while it is staged, because P has to be bf16 for the PV product anyway.
@@ -216,11 +237,18 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[db][i] = 0.0f;
-  float m = -INFINITY;     // reference max of the raw (unscaled) scores of this row (may lag the true max by < 2^THR)
+  float m = -INFINITY;     // reference max of this row's scores (may lag the true max by < 2^THR); units: raw scores, PRE: log2 units
   float mthr = -INFINITY;  // m + threshold: a tile max above it forces a rescale
   float l = 0.0f;          // this lane half's share of the running sum
   const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
-  const float thr_raw = FA_DEFER_THR / c2;         // the threshold in raw-score units
+  const float cm = PRE ? 1.0f : c2;                // m's units -> log2 units
+  const float thr_raw = FA_DEFER_THR / cm;         // the threshold in m's units
+  // PRE: -m in all 16 registers of a tuple = the C operand of each score chain's first MFMA (0 until the first tile has
+  // set m: the first tile's scores come out raw and go through the exact path)
+  f32x16 negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.0f;
+  if constexpr (PRE) asm volatile("" : "+v"(negm));  // opaque: else hipcc re-materialises the splat in front of every MFMA
 
   stage_load(sp);  // this split's first tile (past the end of a short head: zeros through the descriptor, never used)
   stage_write(0);
@@ -231,6 +259,12 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
 #pragma unroll
     for (int j = 0; j < NS8; ++j) asm volatile("" : "+v"(qf8[j]));
   } else {
+    if constexpr (PRE) {  // Q~ = round(c.Q), once per block
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (elem)((float)qf[ks][j] * c2);
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
   }
@@ -311,15 +345,26 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
           for (int i = 0; i < 16; ++i) s[kb][i] = 0.0f;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            s[kb] = M::mfma(kf[kb][ks], qf[ks], s[kb]);
-            constexpr int PER = (2 * 2 * DB) / (2 * KS);  // V block reads per QK MFMA (1 at D=64)
+            s[kb] = M::mfma(kf[kb][ks], qf[ks], (PRE && ks == 0) ? negm : s[kb]);
+            if constexpr (FA_VPRE_HALF) {  // the 2 * DB V blocks of keys 0..31, one per two QK MFMAs
+              const int mm = kb * KS + ks;
+              if ((mm & 1) == 0) {
+                const int m = mm >> 1;
+                const int vst = (m / DB) % 2, vdb = m % DB;
+                const lds_char *vb = vptr[vdb] + buf * TILE + (16 * vst) * RB;
+                vlo[0][vst][vdb] = lds_read_tr16(vb);
+                vhi[0][vst][vdb] = lds_read_tr16(vb + 8 * RB);
+              }
+            } else {
+              constexpr int PER = (2 * 2 * DB) / (2 * KS);  // V block reads per QK MFMA (1 at D=64)
 #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-              const int m = (kb * KS + ks) * PER + u;
-              const int vkb = m / (2 * DB), vst = (m / DB) % 2, vdb = m % DB;
-              const lds_char *vb = vptr[vdb] + buf * TILE + (32 * vkb + 16 * vst) * RB;
-              vlo[vkb][vst][vdb] = lds_read_tr16(vb);
-              vhi[vkb][vst][vdb] = lds_read_tr16(vb + 8 * RB);
+              for (int u = 0; u < PER; ++u) {
+                const int m = (kb * KS + ks) * PER + u;
+                const int vkb = m / (2 * DB), vst = (m / DB) % 2, vdb = m % DB;
+                const lds_char *vb = vptr[vdb] + buf * TILE + (32 * vkb + 16 * vst) * RB;
+                vlo[vkb][vst][vdb] = lds_read_tr16(vb);
+                vhi[vkb][vst][vdb] = lds_read_tr16(vb + 8 * RB);
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -353,7 +398,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
         for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
-          s[i / KS] = M::mfma(kf[i], qf[i % KS], (i % KS) == 0 ? zero : s[i / KS]);
+          s[i / KS] = M::mfma(kf[i], qf[i % KS], (i % KS) == 0 ? (PRE ? negm : zero) : s[i / KS]);
           if (i + LA < NK) kread(i + LA);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -383,7 +428,8 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
       __builtin_amdgcn_s_setprio(0);
 #endif
       // ---- online softmax, lane-local + one half swap
-      const float mc_old = m * c2;
+      const float mc_old = m * c2;  // (unused with PRE)
+      (void)mc_old;
       float ls0 = 0.0f, ls1 = 0.0f;
 #if FA_SUMTRIG
       // Deferred row max (T13) WITHOUT a per-tile max: P = exp2(c.s - c.m) is formed with the running reference m, and
@@ -396,10 +442,15 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
       if (t != sp) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc_old));
-          s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mc_old));
-          ls0 += s[0][i];
-          ls1 += s[1][i];
+          if constexpr (PRE) {  // the matrix core has already subtracted m
+            s[0][i] = __builtin_amdgcn_exp2f(s[0][i]);
+            s[1][i] = __builtin_amdgcn_exp2f(s[1][i]);
+          } else {
+            s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc_old));
+            s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mc_old));
+          }
+          ls0 = (i == 0) ? s[0][i] : ls0 + s[0][i];  // (0 + x is an instruction: -ffp-contract/-0.0 rules keep it)
+          ls1 = (i == 0) ? s[1][i] : ls1 + s[1][i];
         }
         exact = __builtin_amdgcn_ballot_w64(ls0 + ls1 > sum_thr) != 0;  // wave-uniform
         if (exact) recompute_scores(bufc, s, kv0, need_mask);
@@ -423,7 +474,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
         // (rescale whenever a max moved) paid the 32-multiply O pass nearly every tile.
         if (FA_SUMTRIG || __builtin_amdgcn_ballot_w64(mx > mthr) != 0) {  // wave-uniform; first tile: mthr = -inf
           const float m_new = fmaxf(m, mx);
-          const float alpha = __builtin_amdgcn_exp2f((m - m_new) * c2);
+          const float alpha = __builtin_amdgcn_exp2f((m - m_new) * cm);
           l *= alpha;
 #pragma unroll
           for (int db = 0; db < DB; ++db)
@@ -431,14 +482,19 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
             for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
           m = m_new;
           mthr = m_new + thr_raw;
+          if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) negm[i] = -m_new;
+            asm volatile("" : "+v"(negm));
+          }
         }
-        const float mc = m * c2;
+        const float mc = m * cm;
         ls0 = 0.0f;
         ls1 = 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mc));
-          s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mc));
+          s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], cm, -mc));
+          s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], cm, -mc));
           ls0 += s[0][i];
           ls1 += s[1][i];
         }
@@ -462,6 +518,14 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
             for (int db = 0; db < DB; ++db) {
               const s16x8 v8 = __builtin_shufflevector(vlo[kb][st][db], vhi[kb][st][db], 0, 1, 2, 3, 4, 5, 6, 7);
               oacc[db] = M::mfma(__builtin_bit_cast(vec8, v8), pf, oacc[db]);
+              if constexpr (FA_VPRE_HALF) {
+                if (kb == 0) {  // keys 32..63: the same block of the second half, read behind the MFMA that frees its registers' twin
+                  const lds_char *vb = vptr[db] + buf * TILE + (32 + 16 * st) * RB;
+                  vlo[1][st][db] = lds_read_tr16(vb);
+                  vhi[1][st][db] = lds_read_tr16(vb + 8 * RB);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
             }
           }
         }
@@ -520,7 +584,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
     if (sp == 0) {
       const float m1 = mb[NACC * 64], l1 = mb[(NACC + 1) * 64];
       const float mm = fmaxf(m, m1);  // split 0 owns tile 0: m is finite
-      const float a0 = __builtin_amdgcn_exp2f((m - mm) * c2), a1 = __builtin_amdgcn_exp2f((m1 - mm) * c2);
+      const float a0 = __builtin_amdgcn_exp2f((m - mm) * cm), a1 = __builtin_amdgcn_exp2f((m1 - mm) * cm);
 #pragma unroll
       for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -541,7 +605,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
     }
     const float inv_l = 1.0f / l;
     if (p.lse != nullptr && h == 0 && qrow < p.N)
-      p.lse[(long long)bh * p.N + qrow] = m * p.scale + logf(l);
+      p.lse[(long long)bh * p.N + qrow] = m * (PRE ? 0.6931471805599453f : p.scale) + logf(l);
 #pragma unroll
     for (int db = 0; db < DB; ++db) {
 #pragma unroll
@@ -573,14 +637,14 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   }
 }
 
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, bool PRESC>
 __global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
-  fwd_mfma_body<Tag, D, CAUSAL, 1>(p);
+  fwd_mfma_body<Tag, D, CAUSAL, 1, PRESC>(p);
 }
 
 template <typename Tag, int D, bool CAUSAL>
 __global__ __launch_bounds__(2 * NTHREADS, 2) void fwd_mfma_split2_kernel(Params p) {
-  fwd_mfma_body<Tag, D, CAUSAL, 2>(p);
+  fwd_mfma_body<Tag, D, CAUSAL, 2, true>(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -589,12 +653,12 @@ bool mfma_supported(int dtype, int D) {
   return dtype == FA_DTYPE_FP8_E4M3 && (D == 64 || D == 128 || D == 256);  // an fp8 row must fill whole 16-byte chunks per thread
 }
 
-template <typename Tag, int D, bool CAUSAL>
-static hipError_t launch_one(const Params &p, hipStream_t s) {
+template <typename Tag, int D, bool CAUSAL, bool PRESC>
+static hipError_t launch_one_(const Params &p, hipStream_t s) {
   const int nQ = (p.N + BM - 1) / BM;
   const size_t vrow = (D == 96) ? 256 : D * 2;  // fp8: K tiles stay e4m3 (rows of D bytes), V tiles are widened to bf16
   const size_t smem = 2 * BN * (std::is_same<Tag, FP8>::value ? (size_t)D : vrow) + 2 * BN * vrow;
-  auto kern = fwd_mfma_kernel<Tag, D, CAUSAL>;
+  auto kern = fwd_mfma_kernel<Tag, D, CAUSAL, PRESC>;
   if (smem > 48 * 1024) {
     hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
     if (e != hipSuccess) return e;
@@ -609,6 +673,16 @@ static hipError_t launch_one(const Params &p, hipStream_t s) {
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
   hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
   return hipGetLastError();
+}
+
+// p.exact (variant mfma_exact) selects the instantiation without the pre-scaled operand; where the pre-scaling does not
+// exist (fp8, head_dim 256) there is only that one.
+template <typename Tag, int D, bool CAUSAL>
+static hipError_t launch_one(const Params &p, hipStream_t s) {
+  if constexpr (prescale_applies<Tag, D>()) {
+    if (!p.exact) return launch_one_<Tag, D, CAUSAL, true>(p, s);
+  }
+  return launch_one_<Tag, D, CAUSAL, false>(p, s);
 }
 
 template <typename Tag, int D, bool CAUSAL>

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FA_MI355_VERSION 201 /* major*10000 + minor*100 + patch */
+#define FA_MI355_VERSION 300 /* major*10000 + minor*100 + patch */
 
 /* element type of Q, K, V and O */
 enum fa_dtype {
@@ -58,9 +58,12 @@ enum fa_variant {
                             32-row blocks of a wave share every K/V fragment (head_dim 128, long sequences) */
   FA_VARIANT_MFMA_SPLITKV = 6, /* same operator for small grids: one 32-row query block per workgroup, its keys split over
                             2-8 waves and merged in LDS through the row LSE (short sequences / few heads) */
-  FA_VARIANT_MFMA_SPLIT2 = 7 /* same operator for grids that fill part of the chip: the 128-row workgroup of MFMA with eight
+  FA_VARIANT_MFMA_SPLIT2 = 7, /* same operator for grids that fill part of the chip: the 128-row workgroup of MFMA with eight
                             waves, waves 0-3 / 4-7 taking the even / odd KV tiles and merging once (halves the sequential
                             tile count of a block; head_dim 64, 128) */
+  FA_VARIANT_MFMA_EXACT = 8 /* FA_VARIANT_MFMA without the pre-scaled query operand: every score is scaled in fp32 (one more
+                            FMA per score, 6-8 % slower at head_dim 64). For logits far larger than a trained model
+                            produces; see "LSE accuracy" below. Identical to FA_VARIANT_MFMA for fp8 inputs and D = 256 */
 };
 
 /* status codes (0 = success, negative = error; text via fa_last_error()) */
@@ -90,6 +93,18 @@ enum fa_status {
  * Inputs are expected to be finite: the matrix-core kernels are compiled without NaN handling (their
  * own -inf mask values never meet anything that could produce one), so NaN/Inf in Q, K or V give
  * unspecified output values (never a fault).
+ *
+ * LSE accuracy. The reference never checks L_out (main.mm:1083 only feeds it to its backward) and forms its scores in
+ * half precision (kernels.metal:709-712). Here every sum is fp32. FA_VARIANT_MFMA and FA_VARIANT_MFMA_SPLIT2 with
+ * f16 / bf16 inputs and D <= 128 (the kernels FA_VARIANT_AUTO picks for BASELINE configs 2 and 3) multiply the query
+ * operand by scale*log2(e) and round it to the input type ONCE per 128-row block, so that the matrix core delivers
+ * the exponent of every probability directly (replaces the per-score scale-and-subtract of kernels.metal:763-771):
+ * the result is the exact operator applied to a Q' with |Q' - Q| <= eps*|Q| element-wise, eps = 2^-9 (bf16) /
+ * 2^-12 (f16), half an ulp of the input type. Consequently
+ *     |lse - exact| <= 1e-4 + eps * scale * |q_i|_2 * max_j |k_j|_2        (row i),
+ * i.e. relative to the score magnitude (measured on BASELINE config 3, U(-1,1) inputs: max 1.0e-3, rms 4e-5 for
+ * bf16; 1.3e-4 / 5e-6 for f16), while O keeps the tolerance of the other kernels (max|O - exact| 3.1e-3 vs 2.9e-3
+ * without the pre-scaling on config 3). Every other kernel / dtype: |lse - exact| <= 1e-4 for |lse| <= ~10.
  */
 int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
            int B, int H, int N, int D, float scale,

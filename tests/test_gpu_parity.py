@@ -8,19 +8,23 @@ Tolerances (max-abs on O, inputs U(-1,1) so |O| <= 1):
   bf16 MFMA     : 6e-3   (bf16 has 3 fewer mantissa bits than fp16; reference bar for
                           its 16-bit operator is 1e-2, main.mm:452,591)
   LSE           : 2e-5 fp32 kernels, 1e-4 MFMA (fp32 accumulate; unpinned in the reference)
+The kernels that pre-scale the query operand (variants mfma, mfma_split2 for f16/bf16, D <= 128) compute the exact
+operator on Q~ = round(scale*log2e*Q): they are held to the SAME tolerances against the oracle evaluated on that Q~
+(util.effective_q reproduces it bit for bit), and to the bound include/fa_mi355.h states ("LSE accuracy") against the
+oracle on the true Q. Variant mfma_exact is the same kernel without the pre-scaling.
 Index logic (causal mask, tile skip, head/batch addressing) is checked bit-exact.
 """
 import numpy as np
 import pytest
 
-from util import make_qkv, run_op, to_dev
+from util import LN2, effective_q, is_prescaled, lse_tol, make_qkv, o_tol, run_op, to_dev
 
 pytestmark = pytest.mark.gpu
 
 TOL_O = {"f32": 2e-5, "f16": 1.5e-3, "bf16": 6e-3}
 TOL_LSE = {"f32": 2e-5, "f16": 1e-4, "bf16": 1e-4}
 # the matrix-core kernels: 128-row workgroups ("mfma"), paired-block pipeline ("mfma_pp"); "auto" picks by grid size
-MFMA_VARIANTS = ["mfma", "mfma_pp", "mfma_splitkv", "mfma_split2"]
+MFMA_VARIANTS = ["mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact"]
 
 
 def need(fa, dtype, variant, D):
@@ -41,12 +45,19 @@ def fa():
 
 def check(fa, oracle, q, k, v, dtype, causal, variant, tol_scale=1.0, scale=None):
     o, lse = run_op(fa, q, k, v, dtype, causal, variant, scale)
-    o64, lse64 = oracle.attn_fwd_f64(q, k, v, causal, scale)
     assert np.isfinite(o).all() and np.isfinite(lse).all()
+    pre = is_prescaled(fa, dtype, variant, *q.shape, causal)
+    if pre:  # strict: the exact operator on the operand the kernel really multiplies
+        o64, lse64 = oracle.attn_fwd_f64(effective_q(oracle, q, dtype, scale), k, v, causal, LN2)
+        err_o, err_l = np.abs(o - o64).max(), np.abs(lse - lse64).max()
+        assert err_o < TOL_O[dtype] * tol_scale, (variant, dtype, causal, q.shape, err_o, "vs oracle on Q~")
+        assert err_l < TOL_LSE[dtype] * tol_scale, (variant, dtype, causal, q.shape, err_l, "vs oracle on Q~")
+    # against the true Q: the plain tolerances, plus the documented operand-rounding bound where it applies
+    o64, lse64 = oracle.attn_fwd_f64(q, k, v, causal, scale)
     err_o = np.abs(o - o64).max()
     err_l = np.abs(lse - lse64).max()
-    assert err_o < TOL_O[dtype] * tol_scale, (variant, dtype, causal, q.shape, err_o)
-    assert err_l < TOL_LSE[dtype] * tol_scale, (variant, dtype, causal, q.shape, err_l)
+    assert err_o < o_tol(dtype, pre, q, k, v, scale, TOL_O[dtype] * tol_scale), (variant, dtype, causal, q.shape, err_o)
+    assert err_l < lse_tol(dtype, pre, q, k, scale, TOL_LSE[dtype] * tol_scale), (variant, dtype, causal, q.shape, err_l)
     return err_o, err_l
 
 
@@ -128,10 +139,12 @@ def test_fp8_equals_bf16_kernel_on_same_values(fa, oracle_mod, variant):
     for causal in (False, True):
         o8, l8 = run_op(fa, q, k, v, "fp8", causal, variant)
         ob, lb = run_op(fa, q, k, v, "bf16", causal, variant)
-        if variant in ("mfma", "mfma_split2"):
+        if variant in ("mfma", "mfma_split2", "mfma_exact"):
             # these kernels (one body) multiply e4m3 by e4m3 on the scaled fp8 MFMA (64 head-dim elements per instruction): every
             # product is exact, but fp32 partial sums are formed in a different order than in the bf16 instruction, so
             # the scores agree to fp32 rounding, not bit for bit
+            # (and the bf16 kernel pre-scales its query operand, the fp8 score product cannot: compare with mfma_exact)
+            ob, lb = run_op(fa, q, k, v, "bf16", causal, "mfma_exact")
             assert np.abs(l8 - lb).max() < 5e-5  # |lse| <= 7 here; the oracle tolerance for LSE is 1e-4
             assert np.abs(o8 - ob).max() <= 2 ** -7 * np.abs(ob).max()  # a bf16 ulp or two on a few elements
         else:  # e4m3 widened to bf16 while staging: the very same arithmetic
@@ -156,7 +169,9 @@ def test_causal_row0_is_v0_bit_exact(fa, oracle_mod, dtype, variant):
 
 
 @pytest.mark.parametrize("variant,dtype", [("mfma", "bf16"), ("mfma", "f16"), ("mfma_pp", "bf16"), ("mfma_pp", "f16"),
-                                           ("mfma_splitkv", "bf16"), ("mfma_splitkv", "f16"), ("tiled_v2", "f32"), ("tiled", "f32"), ("naive", "f32")])
+                                           ("mfma_splitkv", "bf16"), ("mfma_splitkv", "f16"), ("mfma_split2", "bf16"), ("mfma_split2", "f16"),
+                                           ("mfma_exact", "bf16"), ("mfma", "fp8"), ("mfma_pp", "fp8"), ("mfma_splitkv", "fp8"), ("mfma_split2", "fp8"),
+                                           ("tiled_v2", "f32"), ("tiled", "f32"), ("naive", "f32")])
 def test_mask_index_probe_exact(fa, oracle_mod, variant, dtype):
     # Q = 0 -> uniform softmax; V[j,0] = delta(j,t): causal O[i,0] = 1/(i+1) for i >= t, EXACTLY 0 left of it.
     # t straddles every tile / wave / block boundary of the kernels (32, 64, 128).
@@ -170,14 +185,14 @@ def test_mask_index_probe_exact(fa, oracle_mod, variant, dtype):
         col = o[0, 0, :, 0]
         assert np.array_equal(col[:t], np.zeros(t, np.float32)), (variant, t)
         i = np.arange(N, dtype=np.float32)
-        expect = oracle_mod.round_to(np.float32(1.0) / (i + 1), dtype)
-        ulp = {"f32": 2e-7, "f16": 1e-3, "bf16": 8e-3}[dtype]
+        expect = oracle_mod.round_to(np.float32(1.0) / (i + 1), "bf16" if dtype == "fp8" else dtype)  # fp8 inputs: O is bf16
+        ulp = {"f32": 2e-7, "f16": 1e-3, "bf16": 8e-3, "fp8": 8e-3}[dtype]
         assert np.all(np.abs(col[t:] - expect[t:]) <= ulp * expect[t:]), (variant, t)
         assert np.count_nonzero(o[0, 0, :, 1:]) == 0
         assert np.abs(lse[0, 0] - np.log(i + 1)).max() < 1e-5
         # non-causal: every row sees key t
         o, _ = run_op(fa, q, k, v, dtype, False, variant)
-        assert np.all(np.abs(o[0, 0, :, 0] - oracle_mod.round_to(np.float32(1.0 / N), dtype)) <= ulp / N)
+        assert np.all(np.abs(o[0, 0, :, 0] - oracle_mod.round_to(np.float32(1.0 / N), "bf16" if dtype == "fp8" else dtype)) <= ulp / N)
 
 
 @pytest.mark.parametrize("variant", MFMA_VARIANTS)
@@ -308,8 +323,12 @@ def test_randomized_shapes(fa, oracle_mod, variant):
         o, lse = run_op(fa, q, k, v, dtype, causal, variant, scale)
         o64, l64 = oracle_mod.attn_fwd_f64(q, k, v, causal, scale)
         tol = TOL_O["f16"] if dtype == "f16" else TOL_O["bf16"]
+        pre = is_prescaled(fa, dtype, variant, B, H, N, D, causal)
         assert np.abs(o - o64).max() < tol, (B, H, N, D, dtype, causal, scale)
-        assert np.abs(lse - l64).max() < 1e-4, (B, H, N, D, dtype, causal, scale)
+        assert np.abs(lse - l64).max() < lse_tol(dtype, pre, q, k, scale), (B, H, N, D, dtype, causal, scale)
+        if pre:
+            o64, l64 = oracle_mod.attn_fwd_f64(effective_q(oracle_mod, q, dtype, scale), k, v, causal, LN2)
+            assert np.abs(o - o64).max() < tol and np.abs(lse - l64).max() < 1e-4, (B, H, N, D, dtype, causal, scale)
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
@@ -332,7 +351,10 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
         torch.cuda.synchronize()
         o64, l64 = oracle_mod.attn_fwd_ex_f64(q, k, v, causal)
         assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype], (B, Hq, Hkv, Nq, Nk, D, causal)
-        assert np.abs(lse.cpu().numpy() - l64).max() < 1e-4
+        assert np.abs(lse.cpu().numpy() - l64).max() < lse_tol(dtype, D <= 128, q, k)
+        if D <= 128:  # the generalised entry runs the 128-row kernel with the pre-scaled operand: strict vs the oracle on Q~
+            o64, l64 = oracle_mod.attn_fwd_ex_f64(effective_q(oracle_mod, q, dtype), k, v, causal, LN2)
+            assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype] and np.abs(lse.cpu().numpy() - l64).max() < 1e-4
         if Nq == Nk:  # GQA == MHA on repeated K/V heads, bit for bit
             g = Hq // Hkv
             # (variant "mfma": the generalised entry always runs the 128-row kernel; "auto" may pick another one for a small grid)
@@ -345,7 +367,8 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
         v = oracle_mod.round_to(oracle_mod.init_random(2 * 2 * 333 * 64, 7).reshape(2, 2, 333, 64) * 2, "fp8")
         o8, l8 = fa.flash_attention_forward(to_dev(q, "fp8"), to_dev(k, "fp8"), to_dev(v, "fp8"), is_causal=True)
         ob, lb = fa.flash_attention_forward(to_dev(q, "bf16"), to_dev(k, "bf16"), to_dev(v, "bf16"), is_causal=True)
-        assert (l8 - lb).abs().max().item() < 5e-5 and (o8.float() - ob.float()).abs().max().item() <= 2 ** -7 * ob.float().abs().max().item()
+        assert (l8 - lb).abs().max().item() < lse_tol("bf16", True, q, k, None, 5e-5)
+        assert (o8.float() - ob.float()).abs().max().item() <= 2 ** -6 * ob.float().abs().max().item()
         o64, _ = oracle_mod.attn_fwd_ex_f64(q, k, v, True)
         assert np.abs(o8.float().cpu().numpy() - o64).max() < TOL_O["bf16"] * 2
     x = to_dev(np.zeros((1, 4, 64, 64), np.float32), dtype)
@@ -504,6 +527,49 @@ def test_error_behaviour_on_device(fa):
 # BASELINE.json configurations at FULL size: sampled rows vs the fp64 oracle +
 # size-independent properties
 # --------------------------------------------------------------------------
+def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
+    # FA_VARIANT_AUTO picks among the matrix-core kernels by the grid a shape gives (csrc/fa_api.hip fa_resolve_variant_for;
+    # DESIGN.md section 4). One shape on each side of every boundary, called THROUGH auto: the resolved variant is what
+    # DESIGN says, the result equals that of the kernel called by name bit for bit, and it matches the oracle.
+    import torch
+
+    lib = fa.load_library()
+    V = fa.VARIANTS
+    cases = [  # (B, H, N, D, dtype, causal, expected variant)
+        (1, 8, 1024, 64, "f16", False, "mfma_splitkv"),    # BASELINE config 2: 64 blocks of 128 rows <= 64
+        (1, 8, 1040, 64, "bf16", True, "mfma_split2"),     # 72 blocks: just past the split-KV rule, N >= 512
+        (1, 64, 512, 64, "bf16", True, "mfma_split2"),     # 256 blocks: the last grid of the eight-wave form
+        (1, 65, 512, 64, "bf16", False, "mfma"),           # 260 blocks: first grid of the plain 128-row kernel
+        (1, 80, 256, 64, "bf16", True, "mfma"),            # N < 512: never the eight-wave form
+        (2, 3, 64, 64, "f16", True, "mfma"),               # N <= 64: a single tile, never split-KV
+        (1, 2, 4096, 128, "bf16", True, "mfma_splitkv"),   # head_dim 128, 64 blocks
+        (1, 16, 2048, 128, "bf16", True, "mfma_split2"),   # 256 blocks of 128 rows, N < 4096
+        (1, 32, 4096, 128, "bf16", True, "mfma_pp"),       # 512 blocks of 256 rows, N >= 4096: the paired-block kernel
+        (1, 31, 4096, 128, "bf16", True, "mfma"),          # 496 blocks of 256 rows: below the paired-block rule
+        (1, 4, 300, 96, "bf16", True, "mfma"),             # head dims only the 128-row kernel has
+        (1, 8, 1024, 64, "fp8", True, "mfma_splitkv"),
+        (1, 40, 1024, 64, "fp8", True, "mfma"),
+    ]
+    for (B, H, N, D, dtype, causal, want) in cases:
+        fdt = fa.DTYPES[{"fp8": "fp8_e4m3"}.get(dtype, dtype)]
+        assert lib.fa_resolve_variant_for(fdt, D, B, H, N, int(causal)) == V[want], (B, H, N, D, dtype, causal, want)
+        q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype, seeds=(5, 6, 7))
+        qd, kd, vd = (to_dev(x, dtype) for x in (q, k, v))
+        o_a, l_a = fa.flash_attention_forward(qd, kd, vd, is_causal=causal)  # variant="auto"
+        o_n, l_n = fa.flash_attention_forward(qd, kd, vd, is_causal=causal, variant=want)
+        torch.cuda.synchronize()
+        assert torch.equal(o_a, o_n) and torch.equal(l_a, l_n), (want, "auto did not run the kernel it resolves to")
+        hs = [0, H - 1] if N > 1024 else list(range(H))  # the oracle is O(N^2) per head
+        for h in hs:
+            rows = np.unique(np.concatenate([[0, N // 2, N - 1], np.arange(0, N, max(1, N // 64))])).astype(np.int32)
+            o64, l64 = oracle_mod.attn_rows_f64(q[0, h], k[0, h], v[0, h], rows, causal)
+            pre = is_prescaled(fa, dtype, "auto", B, H, N, D, causal)
+            tol = TOL_O["f16"] if dtype == "f16" else TOL_O["bf16"]
+            assert np.abs(o_a[0, h].float().cpu().numpy()[rows] - o64).max() < tol, (want, h)
+            assert np.abs(l_a[0, h].cpu().numpy()[rows] - l64).max() < lse_tol(dtype, pre, q[0, h], k[0, h]), (want, h)
+
+
+
 def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, variant="auto"):
     import functools
 
@@ -518,12 +584,13 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, varia
     o, lse = fwd(q, k, v, is_causal=causal)
     torch.cuda.synchronize()
     assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    pre = is_prescaled(fa, dtype, variant, B, H, N, D, causal)
     if causal:  # row 0 attends to key 0 only
         assert torch.equal(o[:, :, 0], v[:, :, 0])
         s00 = (q[:, :, 0].float() * k[:, :, 0].float()).sum(-1) * (D ** -0.5)
-        assert torch.allclose(lse[:, :, 0], s00, atol=1e-4)
+        assert torch.allclose(lse[:, :, 0], s00, atol=lse_tol(dtype, pre, q[:, :, :1].float().cpu().numpy(), k[:, :, :1].float().cpu().numpy()))
     rng = np.random.default_rng(7)
-    worst_o = worst_l = 0.0
+    worst_o = worst_l = tol_l = 0.0
     for (b, h) in heads:
         rows = np.unique(np.concatenate([[0, 1, 31, 32, 63, 64, 127, 128, N - 129, N - 128, N - 65, N - 64, N - 1],
                                          rng.integers(0, N, nrows)])).astype(np.int32)
@@ -531,7 +598,12 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, varia
         o64, l64 = oracle_mod.attn_rows_f64(qh, kh, vh, rows, causal)
         worst_o = max(worst_o, np.abs(o[b, h].float().cpu().numpy()[rows] - o64).max())
         worst_l = max(worst_l, np.abs(lse[b, h].cpu().numpy()[rows] - l64).max())
-    assert worst_o < TOL_O[dtype] and worst_l < TOL_LSE[dtype], (worst_o, worst_l)
+        tol_l = max(tol_l, lse_tol(dtype, pre, qh, kh, None, TOL_LSE[dtype]))
+        if pre:  # strict vs the oracle on the operand the kernel multiplies
+            o64, l64 = oracle_mod.attn_rows_f64(effective_q(oracle_mod, qh, dtype), kh, vh, rows, causal, LN2)
+            assert np.abs(o[b, h].float().cpu().numpy()[rows] - o64).max() < TOL_O[dtype]
+            assert np.abs(lse[b, h].cpu().numpy()[rows] - l64).max() < TOL_LSE[dtype]
+    assert worst_o < TOL_O[dtype] and worst_l < tol_l, (worst_o, worst_l)
     # V = const -> O = const (the softmax weights sum to 1), any size
     ones = torch.full_like(v, 0.5)
     o1, _ = fwd(q, k, ones, is_causal=causal)
@@ -542,14 +614,14 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, varia
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_pp", "mfma_splitkv"])
+@pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact"])
 def test_config2_full(fa, oracle_mod, variant):  # seqlen=1024, D=64, B=1, H=8, fp16, non-causal
     # BASELINE configs[1] names the "V2-style tiled kernel": variant tiled_v2 (kernels.metal:462-596) runs it at
     # full size in fp16; the matrix-core kernels are checked on the same tensors
     _full_size(fa, oracle_mod, 1, 8, 1024, 64, "f16", False, [(0, 0), (0, 7)], variant=variant)
 
 
-@pytest.mark.parametrize("variant", ["auto", "mfma", "mfma_pp"])
+@pytest.mark.parametrize("variant", ["auto", "mfma", "mfma_pp", "mfma_exact"])
 def test_config3_full(fa, oracle_mod, variant):  # seqlen=4096, D=64, B=4, H=16, bf16, causal
     _full_size(fa, oracle_mod, 4, 16, 4096, 64, "bf16", True, [(0, 0), (1, 5), (3, 15)], variant=variant)
 
