@@ -32,6 +32,7 @@ import argparse
 import json
 import os
 import subprocess
+import tempfile
 import sys
 import time
 
@@ -91,14 +92,38 @@ def spawn_ranks(args) -> int:
     base = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                 FA_BENCH_CHILD="1")
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # A profiler preload (rocprofv3 -- python bench.py ...) has already initialised the GPU in THIS process: starting
+    # the ranks from it would be an exec hop out of a GPU-initialised process. Profile one rank (--gpus 1) instead.
+    if not args.cpu_gloo_rehearsal and (os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprof" in os.environ.get("LD_PRELOAD", "")):
+        sys.exit("bench.py --gpus N > 1 under a profiler preload is refused: profile with --gpus 1")
     argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
+    out0 = tempfile.TemporaryFile()  # rank 0's stdout (a pipe nobody drains while polling could fill up)
     for r in range(args.gpus):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+        procs.append(subprocess.Popen(argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # poll ALL children: a rank that dies before the first barrier would leave the others waiting for the RCCL/gloo
+    # timeout -- stop them and fail at once instead
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, pr in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = pr.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    pr.terminate()
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    try:
+                        rcs[i] = pr.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        rcs[i] = pr.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
@@ -190,8 +215,10 @@ def main() -> int:
     launches_total = sum(a.elapsed_time(b) for a, b in evs)  # ms over all K launches
     flops_step_rank = fa.algorithmic_flops(1, my, N, D, CAUSAL)
     bytes_step_rank = fa.algorithmic_bytes(1, my, N, D, DTYPE)
+    my_tflops = flops_step_rank * args.steps / elapsed / 1e12  # this rank alone, over its own clock
     flops_per_s, elapsed = ranks.aggregate_throughput(info, flops_step_rank * args.steps, elapsed, dev)
     value = flops_per_s / 1e12
+    per_rank = ranks.gather_over_ranks(info, my_tflops, dev)  # imbalance across the GPUs of the node
 
     c4 = None if args.no_c4 else c4_slice(fa, torch, ranks, info, dev)
 
@@ -225,8 +252,13 @@ def main() -> int:
                        "sharding": f"(batch,head) slices block-distributed over {world} rank(s), no collective",
                        "flops_per_step_per_gpu": flops_step_rank, "bytes_per_step_per_gpu": bytes_step_rank,
                        "time_warmup_launches": warm_launches},
+            # every rank's own rate (its FLOPs over its own wall time); value <= sum of these, = when the ranks finish together
+            "per_rank": {"tflops": [round(x, 2) for x in per_rank], "tflops_min": round(min(per_rank), 2),
+                         "tflops_max": round(max(per_rank), 2)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS_BF16,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_BF16, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS_BF16, 4),
+                         # whole job against the MFMA peak of all N GPUs (achieved/frac above: rank 0's kernel alone)
+                         "frac_whole_job": round(value / (PEAK_TFLOPS_BF16 * world), 4), "traffic": traffic,
                          "traffic_source": traffic_src or "none recorded",
                          "kernel": fa.forward_kernel_name(DTYPE, D, CAUSAL),
                          "kernel_ms_avg": round(avg_ms, 5), "kernel_ms_median": round(kern_ms[len(kern_ms) // 2], 5),
@@ -278,14 +310,19 @@ def c4_slice(fa, torch, ranks, info, dev, iters=10):
 def rehearsal(args, ranks) -> int:
     """The N>1 control path on CPU (gloo): rank discovery, sharding, barrier and the max/sum reductions
     with the real launcher/spawner in front -- what tests/test_sharding.py drives. No kernel runs."""
+    if os.environ.get("FA_BENCH_FAIL_RANK") == os.environ.get("RANK"):  # tests: a rank that dies before the first barrier
+        sys.exit(3)
     info = ranks.init_ranks(use_gpu=False)
     lo, hi = ranks.my_slices(info, B_PER_GPU * H)
     ranks.barrier(info)
     units = float(hi - lo) * args.steps
-    per_s, worst = ranks.aggregate_throughput(info, units, 0.001 * (info.rank + 1))
+    mine = 0.001 * (info.rank + 1)  # rank r "takes" r+1 ms
+    per_s, worst = ranks.aggregate_throughput(info, units, mine)
+    per_rank = ranks.gather_over_ranks(info, units / mine)
     if info.rank == 0:
         print(json.dumps({"rehearsal": True, "n_gpus": info.world, "backend": info.backend, "slices_rank0": [lo, hi],
-                          "slices_total": B_PER_GPU * H * info.world, "units_per_s": per_s, "worst_s": worst}), flush=True)
+                          "slices_total": B_PER_GPU * H * info.world, "units_per_s": per_s, "worst_s": worst,
+                          "per_rank": {"units_per_s": per_rank, "min": min(per_rank), "max": max(per_rank)}}), flush=True)
     ranks.finalize(info)
     return 0
 

@@ -29,20 +29,11 @@
 //   * hot iterations carry no mask code; the wave's last one or two iterations run masked variants
 #include "fa_mfma_common.h"
 
-#ifndef FA_PP_TIOFF
-#define FA_PP_TIOFF 0
-#endif
 #ifndef FA_PP_THR
 #define FA_PP_THR 8.0f  // log2 units: P values are bounded by 2^8 between rescales
 #endif
 #ifndef FA_PP_LA
 #define FA_PP_LA 2      // LDS fragment reads are issued this many fragments (= 2 MFMAs each) ahead of their use
-#endif
-
-#ifdef FA_PP_DBGA0
-#define FA_DBG_POINT(n) do { if (FA_PP_DBGA0 == (n) && !dbg_done) { asm volatile("s_nop 15\n\ts_nop 7"); dbg_a0 = acc_read1<NACC, 16 * TIOFF + 0>(); dbg_a1 = acc_read1<NACC, 16 * TIOFF + 1>(); dbg_done = true; } } while (0)
-#else
-#define FA_DBG_POINT(n) do { } while (0)
 #endif
 
 namespace fa {
@@ -59,15 +50,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
   constexpr int CPR = D / 8;                // 16-byte chunks per row
   constexpr int KS = D / 16;                // k-steps of the QK^T product
   constexpr int DB = D / 32;                // 32-wide d blocks of O^T
-#ifndef FA_PP_TIOFF
-#define FA_PP_TIOFF 0
-#endif
-  constexpr int TIOFF = FA_PP_TIOFF;        // debug: leave the first TIOFF accumulator tuples unused
-  constexpr int NACC_O = (2 * DB + TIOFF) * 16;  // O^T of block x, d block db = a[16(x DB + db) ..+15]
+  constexpr int NACC_O = 2 * DB * 16;            // O^T of block x, d block db = a[16(x DB + db) ..+15]
   constexpr int NACC_Q = NACC_O + 2 * KS * 4;    // + Q fragment (x, ks) = a[NACC_O + 4(x KS + ks) ..+3]
   constexpr bool ASM_STAGE = !std::is_same<Tag, FP8>::value;  // 16-bit inputs: the loop's K/V staging registers are asm-owned too
   constexpr int NST = ASM_STAGE ? 2 * (BN * (D * 2 / 16) / NTHREADS) * 4 : 0;  // a[NACC_Q + 4 i ..+3] = staged chunk i (K chunks, then V chunks)
-  constexpr int NACC = TIOFF ? 224 : NACC_Q + NST;
+  constexpr int NACC = NACC_Q + NST;
   constexpr int TILE = BN * RB;             // bytes of one K (or V) tile in LDS
   constexpr bool IS_FP8 = std::is_same<Tag, FP8>::value;
   constexpr int GB = IS_FP8 ? 1 : 2;
@@ -77,7 +64,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
   constexpr int NCH = BN * GCPR / NTHREADS; // staged 16-byte global chunks per thread per tile
   constexpr int LA = FA_PP_LA;
   constexpr int NU = 16;                    // per block and tile: 16 units of two scores each (unit u: kb = u/8, e = 2(u%8))
-  static_assert(TIOFF || NACC == 96 || NACC == 112 || NACC == 192 || NACC == 224, "head_dim 64 or 128");
+  static_assert(NACC == 96 || NACC == 112 || NACC == 192 || NACC == 224, "head_dim 64 or 128");
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
@@ -219,15 +206,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     }
     static_for<0, 2 * KS>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-#ifdef FA_PP_QVGPR
-      qv[i / KS][i % KS] = qtmp[i];
-#else
       constexpr int R0 = NACC_O + 4 * i;
       acc_write1<NACC, R0 + 0>(qtmp[i][0]);
       acc_write1<NACC, R0 + 1>(qtmp[i][1]);
       acc_write1<NACC, R0 + 2>(qtmp[i][2]);
       acc_write1<NACC, R0 + 3>(qtmp[i][3]);
-#endif
     });
     write_k(0);
     write_v(0);
@@ -255,9 +238,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     l1[x] = 0.0f;
   }
 
-  float dbg_a0 = 0.0f, dbg_a1 = 0.0f;
-  bool dbg_done = false;
-  (void)dbg_a0; (void)dbg_a1; (void)dbg_done;
   // ================= softmax pieces (C = score buffer, x = block) =================
   // The scores come straight out of asm MFMAs and hipcc pads nothing after an asm statement: a VALU read needs
   // >= 11 wait states behind the MFMA. Naming the tuples "+v" makes every later reader depend on this statement
@@ -304,7 +284,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     l0[x] *= alpha;
     l1[x] *= alpha;
     asm volatile("s_nop 15\n\ts_nop 7" ::"v"(alpha));  // MFMA write -> accvgpr read; VALU write -> asm read
-    static_for<0, 16 * DB>([&](auto ic) __attribute__((always_inline)) { acc_scale1<NACC, (TIOFF + x * DB) * 16 + decltype(ic)::value>(alpha); });
+    static_for<0, 16 * DB>([&](auto ic) __attribute__((always_inline)) { acc_scale1<NACC, x * DB * 16 + decltype(ic)::value>(alpha); });
     asm volatile("s_nop 3");                           // accvgpr write -> MFMA read as C
     mref[x] = m_new;
     mthr[x] = m_new + thr_raw;
@@ -375,12 +355,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
       if constexpr (HAS_QK) {
         __builtin_amdgcn_sched_barrier(0);
         constexpr int f = g / 2, x = g % 2, kb = f / KS, ks = f % KS;
-#ifdef FA_PP_QVGPR
-        if constexpr (ks == 0) M::mfma_v0(s[x][kb], kf[f], qv[x][ks]);
-        else M::mfma_v(s[x][kb], kf[f], qv[x][ks]);
-#else
         mfma_v_qacc<Tag, NACC, NACC_O + 4 * (x * KS + ks), ks == 0>(s[x][kb], kf[f]);
-#endif
         if constexpr (x == 1 && f + LA < NF) kread(std::integral_constant<int, f + LA>{});
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -416,7 +391,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     auto pv = [&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
       constexpr int f = g / 2, x = g % 2, kb = f / (2 * DB), st = (f / DB) % 2, db = f % DB;
-      acc_mfma<Tag, NACC, TIOFF + x * DB + db>(vf[f], pfr[x][kb][st]);
+      acc_mfma<Tag, NACC, x * DB + db>(vf[f], pfr[x][kb][st]);
       if constexpr (x == 1 && f + LA < NF) vread(std::integral_constant<int, f + LA>{});
     };
     static_for<0, (LA < NF ? LA : NF)>([&](auto fc) __attribute__((always_inline)) { vread(fc); });
@@ -433,7 +408,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
       pv(gc);
       __builtin_amdgcn_sched_barrier(0);
     });
-    FA_DBG_POINT(4);
     bool rare = false;
     float mxA = 0.0f, mxB = 0.0f;
     if constexpr (HAS_NEXT) {
@@ -442,7 +416,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
       rare = __builtin_amdgcn_ballot_w64(mxA > mthr[0] || mxB > mthr[1]) != 0;
     }
     if (HAS_NEXT && rare) {
-      FA_DBG_POINT(5);
       // deferred max fired: finish this tile's PV bare, THEN rescale, THEN exponentiate tile tn
       static_for<GH, NG>([&](auto gc) __attribute__((always_inline)) {
         pv(gc);
@@ -490,13 +463,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     static_for<0, 2 * KS>([&](auto fc) __attribute__((always_inline)) {
       constexpr int f = decltype(fc)::value, kb = f / KS, ks = f % KS;
       const u32x4 kfr = lds_read_b128(kptr[ks] + kb * 32 * RB);
-#ifdef FA_PP_QVGPR
-      if constexpr (ks == 0) { M::mfma_v0(s[0][kb], kfr, qv[0][ks]); M::mfma_v0(s[1][kb], kfr, qv[1][ks]); }
-      else { M::mfma_v(s[0][kb], kfr, qv[0][ks]); M::mfma_v(s[1][kb], kfr, qv[1][ks]); }
-#else
       mfma_v_qacc<Tag, NACC, NACC_O + 4 * (0 * KS + ks), ks == 0>(s[0][kb], kfr);
       mfma_v_qacc<Tag, NACC, NACC_O + 4 * (1 * KS + ks), ks == 0>(s[1][kb], kfr);
-#endif
     });
     fence_scores();
     sm_mask(I0{}, 0);
@@ -556,11 +524,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
       }
     };
     if (t < nHot) {                               // hot: tile t+1 exists and needs no mask
-      FA_DBG_POINT(1);
       phase_q(T{}, PK{});
-      FA_DBG_POINT(2);
       phase_p(T{}, F{}, PV{}, t + 1, stage);
-      FA_DBG_POINT(3);
     } else if (t < nTw) {
       if (t + 1 < nTw) {                          // cold: tile t+1 is masked
         phase_q(T{}, PK{});
@@ -594,14 +559,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     }
     const float inv_l = 1.0f / l;
     const int qrow = qw0 + 32 * x + r;
-#ifdef FA_PP_DBGA0
-    if (p.lse != nullptr && qrow < p.N && x == 0) p.lse[(long long)bh * p.N + qrow + 32 * h] = (r & 1) ? dbg_a1 : dbg_a0;
-#else
     if (p.lse != nullptr && h == 0 && qrow < p.N) p.lse[(long long)bh * p.N + qrow] = mref[x] * p.scale + logf(l);
-#endif
     static_for<0, DB * 4>([&](auto jc) __attribute__((always_inline)) {
       constexpr int db = decltype(jc)::value / 4, g4 = decltype(jc)::value % 4;
-      constexpr int R0 = 16 * (TIOFF + x * DB + db) + 4 * g4;
+      constexpr int R0 = 16 * (x * DB + db) + 4 * g4;
       elem2 a, b;
       a[0] = (elem)(acc_read1<NACC, R0 + 0>() * inv_l);
       a[1] = (elem)(acc_read1<NACC, R0 + 1>() * inv_l);
@@ -650,16 +611,13 @@ static hipError_t launch_pp_one(const Params &p, hipStream_t s) {
 template <typename Tag>
 static hipError_t launch_pp_dt(const Params &p, hipStream_t s) {
   if (p.D == 64) return p.is_causal ? launch_pp_one<Tag, 64, true>(p, s) : launch_pp_one<Tag, 64, false>(p, s);
-#if FA_PP_TIOFF  // debug builds shift the accumulator map and only fit head_dim 64
-  return hipErrorInvalidValue;
-#else
   return p.is_causal ? launch_pp_one<Tag, 128, true>(p, s) : launch_pp_one<Tag, 128, false>(p, s);
-#endif
 }
 
 hipError_t launch_pp(const Params &p, int dtype, hipStream_t s) {
-#ifdef FA_PP_AUDIT_SUBSET  // tests/test_isa_audit.py: one input type is enough to audit the schedule (compile time)
-  return launch_pp_dt<BF16>(p, s);
+#ifdef FA_PP_AUDIT_SUBSET  // tests/test_isa_audit.py compiles one input type per hipcc process (1 = bf16, 2 = f16, 3 = fp8)
+  (void)dtype;
+  return launch_pp_dt<std::conditional_t<FA_PP_AUDIT_SUBSET == 1, BF16, std::conditional_t<FA_PP_AUDIT_SUBSET == 2, F16, FP8>>>(p, s);
 #else
   if (dtype == FA_DTYPE_FP8_E4M3) return launch_pp_dt<FP8>(p, s);
   return dtype == FA_DTYPE_F16 ? launch_pp_dt<F16>(p, s) : launch_pp_dt<BF16>(p, s);

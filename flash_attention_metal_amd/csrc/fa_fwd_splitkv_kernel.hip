@@ -309,10 +309,13 @@ static hipError_t launch_splitkv_one(const Params &p, hipStream_t s) {
     hipError_t e = set_dyn_lds_once((const void *)kern, 160 * 1024);
     if (e != hipSuccess) return e;
   }
+  // one workgroup per 32-row block: four times the grid fa_fwd's "grid too large" guard (128-row blocks) lets through
+  const long long grid = (long long)nQ * p.B * p.H;
+  if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
   Params pp = p;
   set_block_divisors(pp, nQ, 0);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(64 * S), smem, s, pp);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * S), smem, s, pp);
   return hipGetLastError();
 }
 

@@ -49,8 +49,9 @@ template <> struct MT<F16> {
   FA_MFMA_ASM("v_mfma_f32_32x32x16_f16")
 };
 
-template <> struct MT<FP8> {  // e4m3 inputs: converted to bf16 on the way into registers / LDS (exact),
-  using elem = __bf16;         // bf16 MFMA from there on (non-scaled fp8 MFMA has the same rate), O is bf16
+template <> struct MT<FP8> {  // e4m3 inputs, bf16 P and O: this is the PV product's instruction (and the score product's in the
+  using elem = __bf16;         // kernels that widen K to bf16 while staging). The 128-row kernel multiplies e4m3 by e4m3 on
+                               // v_mfma_scale_f32_32x32x64_f8f6f4 for the scores (fa_mfma_kernel.hip), twice the bf16 rate
   using vec8 = bf16x8;
   __device__ static __forceinline__ f32x16 mfma(vec8 a, vec8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -101,15 +102,8 @@ template <typename Tag, int NACC, int TI>
 __device__ __forceinline__ void acc_mfma(u32x4 a, u32x4 b) {
   constexpr int lo = 16 * TI, hi = lo + 15;
   static_assert(hi < NACC, "accumulator tuple out of range");
-#ifdef FA_DBG_NOP
-#define FA_DBG_PRE "s_nop 15\n\t"
-#define FA_DBG_POST "\n\ts_nop 15"
-#else
-#define FA_DBG_PRE ""
-#define FA_DBG_POST ""
-#endif
-  if constexpr (MfmaOp<Tag>::is_f16) FA_ACC_ASM(NACC, FA_DBG_PRE "v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" FA_DBG_POST ::"v"(a), "v"(b), "i"(lo), "i"(hi));
-  else FA_ACC_ASM(NACC, FA_DBG_PRE "v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" FA_DBG_POST ::"v"(a), "v"(b), "i"(lo), "i"(hi));
+  if constexpr (MfmaOp<Tag>::is_f16) FA_ACC_ASM(NACC, "v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(lo), "i"(hi));
+  else FA_ACC_ASM(NACC, "v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "i"(lo), "i"(hi));
 }
 // d (VGPR tuple) = A(frag, VGPR) * B(a[QR .. QR+3], asm-owned) [+ d]: the score product with Q parked in the accumulation file
 template <typename Tag, int NACC, int QR, bool FIRST>

@@ -65,6 +65,16 @@ def sum_over_ranks(info: RankInfo, value: float, device: Optional[torch.device] 
     return float(t.item())
 
 
+def gather_over_ranks(info: RankInfo, value: float, device: Optional[torch.device] = None) -> list:
+    """Every rank's value, in rank order, on every rank (per-rank throughput for the imbalance fields of bench.py)."""
+    if info.world == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.empty_like(t) for _ in range(info.world)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
 def my_slices(info: RankInfo, slices_per_rank: int):
     """Weak scaling: the global problem has slices_per_rank * world (batch, head) slices; this rank's range."""
     return shard_heads(slices_per_rank * info.world, info.world, info.rank)

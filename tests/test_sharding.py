@@ -93,6 +93,22 @@ def test_bench_entry_as_typed_spawns_ranks_without_a_launcher():
     r = json.loads(line[0])
     assert r["n_gpus"] == 2 and r["backend"] == "gloo" and r["slices_rank0"] == [0, 64] and r["slices_total"] == 128
     assert r["units_per_s"] == pytest.approx((64 * 3 * 2) / 0.002)  # all ranks' units / the slowest rank's time
+    # per-rank rates (the imbalance fields of the bench line): rank r takes r+1 ms for the same 64*3 units
+    assert r["per_rank"]["units_per_s"] == pytest.approx([64 * 3 / 0.001, 64 * 3 / 0.002])
+    assert r["per_rank"]["min"] == pytest.approx(64 * 3 / 0.002) and r["per_rank"]["max"] == pytest.approx(64 * 3 / 0.001)
+
+
+def test_bench_parent_stops_the_other_ranks_when_one_dies():
+    # a rank that dies before the first barrier must not leave the parent (and the surviving ranks) waiting for the
+    # process-group timeout: FA_BENCH_FAIL_RANK makes rank 1 of the rehearsal exit at once
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_PORT="29547", FA_BENCH_FAIL_RANK="1")
+    import time
+
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--cpu-gloo-rehearsal"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode != 0 and time.time() - t0 < 60
 
 
 def test_bench_parent_process_never_imports_torch_or_the_library():

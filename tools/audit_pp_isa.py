@@ -13,6 +13,9 @@ explicit fence on the cold paths); this script checks the ASSEMBLY the compiler 
     forward path (branches propagate the pending state to their target label; loops are iterated
     to a fixed point).
 
+It also checks that nothing but the kernel's own asm names the accumulation registers the kernel owns
+(audit_owned_agprs) and reports each kernel's scratch size.
+
 usage: audit_pp_isa.py file.s [--min-states 12]     exit code 1 and a listing if anything is too close.
 """
 from __future__ import annotations
@@ -120,18 +123,50 @@ def audit_function(name: str, lines, min_states: int):
     return [(name, a, b, r, e, t) for (a, b), (r, e, t) in sorted(violations.items())]
 
 
-def main() -> int:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("asm")
-    ap.add_argument("--min-states", type=int, default=12)
-    ap.add_argument("--match", default="fwd_pp_kernel")
-    a = ap.parse_args()
-    funcs = {}
-    cur = None
-    for ln, t in enumerate(open(a.asm), 1):
+ASM_START, ASM_END = ";;#ASMSTART", ";;#ASMEND"
+AREG_RE = re.compile(r"\ba(?:(\d+)\b|\[(\d+):(\d+)\])")
+
+
+def audit_owned_agprs(name: str, lines):
+    """The kernel OWNS the accumulation registers a[0 : NACC): only its inline asm may name them (O^T, the Q fragments, the
+    staging chunks live there across the whole loop; hipcc knows them only as clobbers). NACC = highest accumulation
+    register any asm block names + 1. Any instruction OUTSIDE ;;#ASMSTART/;;#ASMEND that names a register below NACC is
+    the compiler parking a value of its own there (a spill, a copy): wrong O, silently. Returns (NACC, violations)."""
+    inside = False
+    nacc = 0
+    outside = []  # (lineno, text, lowest a register named)
+    for ln, t in lines:
+        st = t.strip()
+        if st.startswith(ASM_START):
+            inside = True
+            continue
+        if st.startswith(ASM_END):
+            inside = False
+            continue
+        code = st.split(";")[0]
+        if not code or code.startswith("."):
+            continue
+        regs = []
+        for m in AREG_RE.finditer(code):
+            regs += [int(m.group(1))] if m.group(1) is not None else list(range(int(m.group(2)), int(m.group(3)) + 1))
+        if not regs:
+            continue
+        if inside:
+            nacc = max(nacc, max(regs) + 1)
+        else:
+            outside.append((ln, code, min(regs)))
+    return nacc, [(name, ln, code, lo) for ln, code, lo in outside if lo < nacc]
+
+
+def split_kernels(path: str, match: str):
+    """{mangled name: ([(lineno, text)], scratch bytes per lane)} of the kernels whose name contains `match`."""
+    funcs, scratch = {}, {}
+    cur = last = None
+    for ln, t in enumerate(open(path), 1):
         m = re.match(r"^(_Z\w+):", t)
         if m:
-            cur = m.group(1) if a.match in m.group(1) else None
+            cur = m.group(1) if match in m.group(1) else None
+            last = cur
             if cur:
                 funcs[cur] = []
             continue
@@ -139,12 +174,32 @@ def main() -> int:
             funcs[cur].append((ln, t))
             if "s_endpgm" in t:
                 cur = None
-    bad = []
-    for name, lines in funcs.items():
+        elif last and "; ScratchSize:" in t:
+            scratch[last] = int(t.split(":")[1])
+            last = None
+    return {k: (v, scratch.get(k, -1)) for k, v in funcs.items()}
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("asm")
+    ap.add_argument("--min-states", type=int, default=12)
+    ap.add_argument("--match", default="fwd_pp_kernel")
+    a = ap.parse_args()
+    funcs = split_kernels(a.asm, a.match)
+    bad, owned = [], []
+    for name, (lines, scratch) in funcs.items():
         bad += audit_function(name, lines, a.min_states)
-    print(f"audited {len(funcs)} kernels, {len(bad)} accesses closer than {a.min_states} wait states to an MFMA result")
+        nacc, v = audit_owned_agprs(name, lines)
+        owned += v
+        print(f"  {name[:70]}: owns a[0:{nacc}), scratch {scratch} B/lane")
+    print(f"audited {len(funcs)} kernels, {len(bad)} accesses closer than {a.min_states} wait states to an MFMA result, "
+          f"{len(owned)} compiler-made references to asm-owned accumulation registers")
     for name, l0, l1, r, e, t in bad[:40]:
         print(f"  {name[:60]}: MFMA at line {l0} -> line {l1} after {e} states touches {r[0]}{r[1]}: {t}")
+    for name, ln, code, lo in owned[:40]:
+        print(f"  {name[:60]}: line {ln} names a{lo} outside the kernel's asm: {code}")
+    bad += owned
     return 1 if bad else 0
 
 
