@@ -16,6 +16,8 @@
 // Written for CDNA4: a wave is 64 lanes, so a row-per-lane block is a multiple
 // of 64 rows; K/V rows are read from LDS at one address per wave-instruction
 // (hardware broadcast, conflict-free).
+#include <mutex>
+
 #include "fa_common.h"
 
 namespace fa {
@@ -139,10 +141,9 @@ __global__ __launch_bounds__(64) void tiled_kernel(Params p) {
 }
 
 // ---------------------------------------------------------------------------
-// tiled_v2 ("V2"): kernels.metal:462-596. 128 rows per block (2 waves),
-// Bc = 16, K/V tiles double-buffered in LDS as fp32, filled with 128-bit
-// global loads that are issued before the tile's arithmetic and written to the
-// other buffer after it (one barrier per tile).
+// tiled_v2 ("V2"): kernels.metal:462-596. K/V tiles of 16 keys double-buffered in
+// LDS as fp32, filled with 128-bit global loads that are issued before the
+// tile's arithmetic and written to the other buffer after it (one barrier per tile).
 // ---------------------------------------------------------------------------
 template <typename T> struct Vec16B;  // 16-byte global chunk -> floats
 template <> struct Vec16B<float> {
@@ -173,47 +174,73 @@ template <> struct Vec16B<__bf16> {
   }
 };
 
+// A query row is shared by FOUR lanes (each owns D/4 head-dim elements of q and of the accumulator; a score is the sum
+// of four partial dot products, two quad-permute DPP adds), a lane serves TWO rows (every K/V value read from LDS feeds
+// both), a wave therefore holds 32 rows, and the EIGHT waves of a workgroup split the keys of those 32 rows (wave w
+// takes the 16-key tiles t = w, w+8, ... -- strided, so causal blocks stay balanced), each with its own double-buffered
+// fp32 K/V tiles; one merge through LDS by the row maxima at the end.
+// One thread per row (the reference's shape, kernels.metal:462-596, and round 2's) put BASELINE config 2 -- 8 heads x
+// 1024 rows -- on 128 waves of a 1024-SIMD chip: 676 us. This shape gives it 2048 waves.
+constexpr int V2_BR = 32, V2_NW = 8, V2_RPL = 2;
+template <int D> constexpr int v2_bc() { return (D <= 64) ? 16 : 8; }  // keys per tile (128 KiB of LDS per workgroup at D >= 64)
+template <int D> constexpr size_t v2_lds_bytes() {  // the tile buffers, reused by the merge ([NW][RPL * (D/4 + 2)][64] floats)
+  constexpr size_t tiles = (size_t)2 * V2_NW * 2 * v2_bc<D>() * D, merge = (size_t)V2_NW * V2_RPL * (D / 4 + 2) * 64;
+  return (tiles > merge ? tiles : merge) * sizeof(float);
+}
+
 template <typename T, int D>
-__global__ __launch_bounds__(128) void tiled_v2_kernel(Params p) {
-  constexpr int BR = 128, BC = 16;
+__global__ __launch_bounds__(64 * V2_NW, 1) void tiled_v2_kernel(Params p) {
+  constexpr int BR = V2_BR, NW = V2_NW, RPL = V2_RPL;
+  constexpr int BC = v2_bc<D>();
+  constexpr int DS = D / 4;                    // head-dim elements per lane
   constexpr int EPC = Vec16B<T>::N;            // elements per 16-byte chunk
   constexpr int CHUNKS = BC * D / EPC;         // chunks per tile (K or V)
-  constexpr int CPT = (CHUNKS + BR - 1) / BR;  // chunks per thread
-  __shared__ __attribute__((aligned(16))) float Ks[2][BC * D];
-  __shared__ __attribute__((aligned(16))) float Vs[2][BC * D];
+  constexpr int CPT = (CHUNKS + 63) / 64;      // chunks per lane
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // K tiles, then V tiles: [NW][2][BC * D] each
+  auto Ks = [&](int wv, int buf) { return smem + (wv * 2 + buf) * (BC * D); };
+  auto Vs = [&](int wv, int buf) { return smem + ((NW + wv) * 2 + buf) * (BC * D); };
 
-  const int tx = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int rg = lane >> 2, sl = lane & 3;
   const int row0 = blockIdx.x * BR;
-  const int row = row0 + tx;
-  const bool valid = row < p.N;
+  int row[RPL];
+  bool valid[RPL];
   const long long base = (long long)blockIdx.z * p.batch_stride + (long long)blockIdx.y * p.head_stride;
   const T *Q = (const T *)p.q + base, *K = (const T *)p.k + base, *V = (const T *)p.v + base;
   T *O = (T *)p.o + base;
 
-  float qreg[D], acc[D];
+  float qreg[RPL][DS], acc[RPL][DS], m[RPL], l[RPL];
 #pragma unroll
-  for (int c = 0; c < D / EPC; ++c) {
-    float tmp[EPC];
-    Vec16B<T>::load(Q + (long long)row * D + c * EPC, valid, tmp);
+  for (int x = 0; x < RPL; ++x) {
+    row[x] = row0 + 16 * x + rg;
+    valid[x] = row[x] < p.N;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) qreg[c * EPC + e] = tmp[e];
+    for (int c = 0; c < DS / EPC; ++c) {
+      float tmp[EPC];
+      Vec16B<T>::load(Q + (long long)row[x] * D + sl * DS + c * EPC, valid[x], tmp);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) qreg[x][c * EPC + e] = tmp[e];
+    }
+#pragma unroll
+    for (int d = 0; d < DS; ++d) acc[x][d] = 0.0f;
+    m[x] = -INFINITY;
+    l[x] = 0.0f;
   }
-#pragma unroll
-  for (int d = 0; d < D; ++d) acc[d] = 0.0f;
-  float m = -INFINITY, l = 0.0f;
 
   const int last_row = min(row0 + BR, p.N) - 1;
   const int kv_end = p.is_causal ? last_row + 1 : p.N;
   const int ntiles = (kv_end + BC - 1) / BC;
+  const int steps = (ntiles + NW - 1) / NW;    // every wave runs the same number of steps (one barrier each)
 
   float kst[CPT][EPC], vst[CPT][EPC];
   auto issue = [&](int t) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int c = tx + i * BR;
+      const int c = lane + i * 64;
       const int e0 = c * EPC;
       const int r = e0 / D;
-      const bool in = (c < CHUNKS) && (t * BC + r < p.N);
+      const bool in = (c < CHUNKS) && (t < ntiles) && (t * BC + r < p.N);
       const long long g = (long long)(t * BC) * D + e0;
       Vec16B<T>::load(K + g, in, kst[i]);
       Vec16B<T>::load(V + g, in, vst[i]);
@@ -222,77 +249,136 @@ __global__ __launch_bounds__(128) void tiled_v2_kernel(Params p) {
   auto commit = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      const int c = tx + i * BR;
+      const int c = lane + i * 64;
       if (c < CHUNKS) {
 #pragma unroll
         for (int e = 0; e < EPC; e += 4) {
-          *reinterpret_cast<float4 *>(&Ks[buf][c * EPC + e]) =
+          *reinterpret_cast<float4 *>(Ks(w, buf) + c * EPC + e) =
               make_float4(kst[i][e], kst[i][e + 1], kst[i][e + 2], kst[i][e + 3]);
-          *reinterpret_cast<float4 *>(&Vs[buf][c * EPC + e]) =
+          *reinterpret_cast<float4 *>(Vs(w, buf) + c * EPC + e) =
               make_float4(vst[i][e], vst[i][e + 1], vst[i][e + 2], vst[i][e + 3]);
         }
       }
     }
   };
+  // sum over the four lanes of a row: quad_perm [1,0,3,2] then [2,3,0,1]
+  auto quad_sum = [](float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    return x;
+  };
 
-  issue(0);
+  issue(w);
   commit(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < ntiles) issue(t + 1);  // in flight under this tile's arithmetic
-    const int kv0 = t * BC;
-    float s[BC];
-    float tmax = -INFINITY;
+  for (int st = 0; st < steps; ++st) {
+    const int t = st * NW + w;
+    const int buf = st & 1;
+    if (st + 1 < steps) issue(t + NW);  // in flight under this tile's arithmetic
+    if (t < ntiles) {
+      const int kv0 = t * BC;
+      float s[RPL][BC];
+      float tmax[RPL];
 #pragma unroll
-    for (int j = 0; j < BC; ++j) {
-      const float4 *kr = reinterpret_cast<const float4 *>(&Ks[buf][j * D]);
-      float a = 0.0f;
-#pragma unroll
-      for (int c = 0; c < D / 4; ++c) {
-        const float4 kk = kr[c];
-        a += qreg[4 * c] * kk.x + qreg[4 * c + 1] * kk.y + qreg[4 * c + 2] * kk.z + qreg[4 * c + 3] * kk.w;
-      }
-      a *= p.scale;
-      const int key = kv0 + j;
-      const bool vis = key < p.N && (!p.is_causal || key <= row);
-      s[j] = vis ? a : -INFINITY;
-      tmax = fmaxf(tmax, s[j]);
-    }
-    // per-tile online softmax; a fully masked tile leaves the state untouched
-    const float m_new = fmaxf(m, tmax);
-    if (m_new != -INFINITY) {
-      const float alpha = expf(m - m_new);
-      float psum = 0.0f;
-#pragma unroll
-      for (int d = 0; d < D; ++d) acc[d] *= alpha;
+      for (int x = 0; x < RPL; ++x) tmax[x] = -INFINITY;
 #pragma unroll
       for (int j = 0; j < BC; ++j) {
-        const float pj = expf(s[j] - m_new);
-        psum += pj;
-        const float4 *vr = reinterpret_cast<const float4 *>(&Vs[buf][j * D]);
+        const float4 *kr = reinterpret_cast<const float4 *>(Ks(w, buf) + j * D + sl * DS);
+        float a[RPL];
 #pragma unroll
-        for (int c = 0; c < D / 4; ++c) {
-          const float4 vv = vr[c];
-          acc[4 * c] += pj * vv.x;
-          acc[4 * c + 1] += pj * vv.y;
-          acc[4 * c + 2] += pj * vv.z;
-          acc[4 * c + 3] += pj * vv.w;
+        for (int x = 0; x < RPL; ++x) a[x] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < DS / 4; ++c) {
+          const float4 kk = kr[c];
+#pragma unroll
+          for (int x = 0; x < RPL; ++x)  // explicit FMAs: the file is built with -ffp-contract=off (a mul + an add per MAC otherwise)
+            a[x] = __builtin_fmaf(qreg[x][4 * c + 3], kk.w, __builtin_fmaf(qreg[x][4 * c + 2], kk.z,
+                   __builtin_fmaf(qreg[x][4 * c + 1], kk.y, __builtin_fmaf(qreg[x][4 * c], kk.x, a[x]))));
+        }
+        const int key = kv0 + j;
+#pragma unroll
+        for (int x = 0; x < RPL; ++x) {
+          const float sc = quad_sum(a[x]) * p.scale;
+          const bool vis = key < p.N && (!p.is_causal || key <= row[x]);
+          s[x][j] = vis ? sc : -INFINITY;
+          tmax[x] = fmaxf(tmax[x], s[x][j]);
         }
       }
-      l = l * alpha + psum;
-      m = m_new;
+      // per-tile online softmax; a fully masked tile leaves a row's state untouched (its weights below are all 0)
+      float pj[RPL][BC];
+#pragma unroll
+      for (int x = 0; x < RPL; ++x) {
+        const float m_new = fmaxf(m[x], tmax[x]);
+        const bool any = m_new != -INFINITY;
+        // exp(x) = 2^(x log2 e) on the hardware exponential (1 ulp; expf's range handling costs ~10 instructions per call)
+        const float alpha = any ? __builtin_amdgcn_exp2f((m[x] - m_new) * 1.4426950408889634f) : 1.0f;
+        float psum = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DS; ++d) acc[x][d] *= alpha;
+#pragma unroll
+        for (int j = 0; j < BC; ++j) {
+          pj[x][j] = any ? __builtin_amdgcn_exp2f((s[x][j] - m_new) * 1.4426950408889634f) : 0.0f;
+          psum += pj[x][j];
+        }
+        l[x] = l[x] * alpha + psum;
+        m[x] = m_new;
+      }
+#pragma unroll
+      for (int j = 0; j < BC; ++j) {
+        const float4 *vr = reinterpret_cast<const float4 *>(Vs(w, buf) + j * D + sl * DS);
+#pragma unroll
+        for (int c = 0; c < DS / 4; ++c) {
+          const float4 vv = vr[c];
+#pragma unroll
+          for (int x = 0; x < RPL; ++x) {
+            acc[x][4 * c] = __builtin_fmaf(pj[x][j], vv.x, acc[x][4 * c]);
+            acc[x][4 * c + 1] = __builtin_fmaf(pj[x][j], vv.y, acc[x][4 * c + 1]);
+            acc[x][4 * c + 2] = __builtin_fmaf(pj[x][j], vv.z, acc[x][4 * c + 2]);
+            acc[x][4 * c + 3] = __builtin_fmaf(pj[x][j], vv.w, acc[x][4 * c + 3]);
+          }
+        }
+      }
     }
-    if (t + 1 < ntiles) commit(buf ^ 1);
+    if (st + 1 < steps) commit(buf ^ 1);
     __syncthreads();
   }
-  if (!valid) return;
-  const float inv = 1.0f / l;
+
+  // ---- merge the key splits (a wave that saw no visible key of a row has m = -inf, l = 0: weight 0)
+  constexpr int MW = RPL * (DS + 2);  // floats per (wave, lane)
+  float *mb = smem;                   // [NW][MW][64] floats inside the tile buffers (all reads are done: last barrier)
+  static_assert((size_t)NW * MW * 64 * sizeof(float) <= v2_lds_bytes<D>(), "merge buffer fits the LDS allocation");
 #pragma unroll
-  for (int d = 0; d < D; ++d) st_elem(O, (long long)row * D + d, acc[d] * inv);
-  if (p.lse) {
+  for (int x = 0; x < RPL; ++x) {
+#pragma unroll
+    for (int d = 0; d < DS; ++d) mb[(w * MW + x * (DS + 2) + d) * 64 + lane] = acc[x][d];
+    mb[(w * MW + x * (DS + 2) + DS) * 64 + lane] = m[x];
+    mb[(w * MW + x * (DS + 2) + DS + 1) * 64 + lane] = l[x];
+  }
+  __syncthreads();
+  if (w >= RPL) return;  // wave x finishes row set x
+  const int x = w;
+  const int orow = row0 + 16 * x + rg;
+  if (orow >= p.N) return;
+  float M = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < NW; ++u) M = fmaxf(M, mb[(u * MW + x * (DS + 2) + DS) * 64 + lane]);
+  float L = 0.0f, out[DS];
+#pragma unroll
+  for (int d = 0; d < DS; ++d) out[d] = 0.0f;
+#pragma unroll
+  for (int u = 0; u < NW; ++u) {
+    const float mu = mb[(u * MW + x * (DS + 2) + DS) * 64 + lane];
+    const float wu = (mu == -INFINITY) ? 0.0f : expf(mu - M);
+    L += wu * mb[(u * MW + x * (DS + 2) + DS + 1) * 64 + lane];
+#pragma unroll
+    for (int d = 0; d < DS; ++d) out[d] += wu * mb[(u * MW + x * (DS + 2) + d) * 64 + lane];
+  }
+  const float inv = 1.0f / L;
+#pragma unroll
+  for (int d = 0; d < DS; ++d) st_elem(O, (long long)orow * D + sl * DS + d, out[d] * inv);
+  if (p.lse && sl == 0) {
     const long long bh = (long long)blockIdx.z * p.H + blockIdx.y;
-    p.lse[bh * p.N + row] = m + logf(l);
+    p.lse[bh * p.N + orow] = M + logf(L);
   }
 }
 
@@ -335,10 +421,30 @@ hipError_t launch_tiled(const Params &p, int dtype, hipStream_t s) {
   FA_DISPATCH_TD(tiled_kernel, grid, block);
   return hipGetLastError();
 }
-hipError_t launch_tiled_v2(const Params &p, int dtype, hipStream_t s) {
-  dim3 grid((p.N + 127) / 128, p.H, p.B), block(128);
-  FA_DISPATCH_TD(tiled_v2_kernel, grid, block);
+template <typename T, int D>
+static hipError_t launch_tiled_v2_one(const Params &p, hipStream_t s) {
+  auto kern = tiled_v2_kernel<T, D>;
+  static std::once_flag once[8];  // per device ordinal (the attribute is per device)
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  hipError_t attr = hipSuccess;
+  std::call_once(once[dev & 7], [&] { attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_lds_bytes<D>()); });
+  if (attr != hipSuccess) return attr;
+  dim3 grid((p.N + V2_BR - 1) / V2_BR, p.H, p.B), block(64 * V2_NW);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(kern, grid, block, v2_lds_bytes<D>(), s, p);
   return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_tiled_v2_t(const Params &p, hipStream_t s) {
+  if (p.D == 32) return launch_tiled_v2_one<T, 32>(p, s);
+  if (p.D == 64) return launch_tiled_v2_one<T, 64>(p, s);
+  return launch_tiled_v2_one<T, 128>(p, s);
+}
+hipError_t launch_tiled_v2(const Params &p, int dtype, hipStream_t s) {
+  if (dtype == FA_DTYPE_F32) return launch_tiled_v2_t<float>(p, s);
+  return dtype == FA_DTYPE_F16 ? launch_tiled_v2_t<_Float16>(p, s) : launch_tiled_v2_t<__bf16>(p, s);
 }
 
 }  // namespace fa
