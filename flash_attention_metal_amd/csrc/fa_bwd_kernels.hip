@@ -15,13 +15,21 @@
 //                        dV^T += dO^T.P,  dK^T += Q^T.dS
 //
 // S and dP are computed twice (7 matrix products instead of 5) in exchange for deterministic,
-// atomic-free, bitwise reproducible gradients. Both kernels reuse the forward's machinery
+// atomic-free, bitwise reproducible gradients. (The single-pass 5-product form sums dQ across key blocks with float
+// atomics: at head_dim 64 that is 570 MB of adds for BASELINE config 3's shape, 440 us at the chip's 1.3 TB/s atomic
+// rate (MI355X_MICROARCH.md, Global float atomics) -- as long as both kernels here together.)
+// Round 3: the row constants ride in the accumulators (cdna guide, attention backward): the operand held in registers is
+// pre-scaled by scale*log2(e) (Q~ in the dQ kernel -- bit for bit the forward's operand --, K~ in the dK/dV kernel) and the
+// score chains start from -LSE*log2(e), the dP chains from -delta, so P = exp2(S') and dS = P * dP' are one
+// transcendental and one multiply per score; the softmax scale is applied once to the finished dQ / dK. Both kernels reuse the forward's machinery
 // (fa_mfma_kernel.hip): one operand's fragments live in registers, the other side streams
 // through double-buffered LDS tiles; the score tile comes out of v_mfma_f32_32x32x16 with the
 // reduction index of the NEXT product in its registers, so P / dS feed that product as the B
 // operand without leaving the register file, and the transposed A operands (K^T, dO^T, Q^T) are
-// ds_read_b64_tr_b16 reads of row-major tiles. A tile that is read both by rows and transposed
-// is kept in LDS twice, once per conflict-free swizzle.
+// ds_read_b64_tr_b16 reads of row-major tiles. A tile that is read both by rows and transposed sits in LDS ONCE, under a
+// chunk swizzle that keeps both kinds of read (and the staging stores) free of bank conflicts (cdna guide T10, "one image
+// for row reads and transposed reads"; round 2 kept two images and paid the LDS store bandwidth twice -- these kernels
+// are LDS-bound: every MFMA takes a 1 KiB fragment from LDS, half the LDS bandwidth at full matrix rate, before any store).
 #include "fa_mfma_common.h"
 
 namespace fa {
@@ -48,9 +56,16 @@ constexpr float LOG2E = 1.4426950408889634f;
   constexpr int BKS = BD / 16;     /* k-steps over the head dim */                               \
   constexpr int BDB = BD / 32;     /* 32-wide output blocks over the head dim */                 \
   constexpr int BTILE = BN * BRB;  /* one 64-row tile image */                                   \
-  auto row_swz = [](int row) { return BD == 64 ? ((row >> 1) & 7) : (row & 15); };        /* row-read image (ds_read_b128) */ \
-  auto tr_swz = [](int row) { return BD == 64 ? (((row >> 1) & 1) << 2) : ((row & 3) << 2); }; /* transposed-read image */ \
-  (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)row_swz; (void)tr_swz
+  /* XOR on the 16-byte chunk index of a row: conflict-free for ds_read_b128 row reads, ds_read_b64_tr_b16 and ds_write_b128 */ \
+  auto u_swz = [](int row) { return BD == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 3) & 3)) : (((row & 3) << 2) | ((row >> 2) & 3)); }; \
+  /* transposed read of the 4-row x 32-column block (R0 + 4h + vq, columns 32db ..), R0 a multiple of 8: the swizzle's low   */ \
+  /* bits depend on R0 only through `variant` = (R0 >> 3) & 3 (head_dim 64) or (R0 >> 3) & 1 (head_dim 128): NTV base addresses */ \
+  constexpr int NTV = BD == 64 ? 4 : 2;                                                       \
+  auto tr_off = [&](int variant, int db, int h_, int g1_, int vq_, int vp_) {                 \
+    const int row = 8 * variant + 4 * h_ + vq_; /* a representative R0 = 8 * variant */        \
+    return (4 * h_ + vq_) * BRB + ((((4 * db) + 2 * g1_ + (vp_ >> 1)) ^ u_swz(row)) << 4) + 8 * (vp_ & 1); \
+  };                                                                                          \
+  (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)u_swz; (void)tr_off; (void)NTV
 
 // ---------------------------------------------------------------------------
 template <typename elem, int D>
@@ -86,9 +101,8 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   using elem = typename M::elem;
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
-  lds_char *KR = smem;               // [2] K tile, row-read image
-  lds_char *KT = smem + 2 * BTILE;   // [2] K tile, transposed-read image
-  lds_char *VR = smem + 4 * BTILE;   // [2] V tile, row-read image
+  lds_char *KU = smem;               // [2] K tile (read by rows for S, transposed for dQ)
+  lds_char *VR = smem + 2 * BTILE;   // [2] V tile (read by rows)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,29 +125,33 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
     qf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * BRB + (2 * ks + h) * 16, 0, 0));
     dof[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)qrow * BRB + (2 * ks + h) * 16, 0, 0));
   }
-  // p*scale = exp2(c2*s - (lse*log2e - log2 scale)); rows past N get p = 0
+  // S' = K.Q~ - lse*log2e straight out of the matrix core (rows past N: -inf, p = 0); dP' = V.dO - delta likewise
   const bool qvalid = qrow < p.N;
-  const float lse2 = qvalid ? p.lse[(long long)bh * p.N + qrow] * LOG2E - __log2f(p.scale) : INFINITY;
+  const float lse2 = qvalid ? p.lse[(long long)bh * p.N + qrow] * LOG2E : INFINITY;
   const float dlt = qvalid ? p.delta[(long long)bh * p.N + qrow] : 0.0f;
   const float c2 = p.scale * LOG2E;
+  f32x16 nlse, ndlt;  // the row constants, one per lane, in all 16 registers of a tuple: C operands of the chains' first MFMAs
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { nlse[i] = -lse2; ndlt[i] = -dlt; }
+  asm volatile("" : "+v"(nlse), "+v"(ndlt));  // opaque: else hipcc re-materialises the splats in front of every MFMA
 
-  const int kx = row_swz(r);
+  const int kx = u_swz(r);
   int koff[BKS];
 #pragma unroll
   for (int ks = 0; ks < BKS; ++ks) koff[ks] = r * BRB + (((2 * ks + h) ^ kx) << 4);
   const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
-  const int vx = tr_swz(vq);
-  int voff[BDB];
+  int voff[NTV][BDB];
 #pragma unroll
-  for (int db = 0; db < BDB; ++db) voff[db] = (4 * h + vq) * BRB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
+  for (int tv = 0; tv < NTV; ++tv)
+#pragma unroll
+    for (int db = 0; db < BDB; ++db) voff[tv][db] = tr_off(tv, db, h, g1, vq, vp);
   constexpr int NCH = BN * BCPR / NTHREADS;  // 2
-  int st_g[NCH], st_r[NCH], st_t[NCH];
+  int st_g[NCH], st_r[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = tid + i * NTHREADS, row = c / BCPR, ch = c % BCPR;
     st_g[i] = row * BRB + ch * 16;
-    st_r[i] = row * BRB + ((ch ^ row_swz(row)) << 4);
-    st_t[i] = row * BRB + ((ch ^ tr_swz(row)) << 4);
+    st_r[i] = row * BRB + ((ch ^ u_swz(row)) << 4);
   }
   const int kv_end = CAUSAL ? min(p.N, q0 + BM) : p.N;
   const int nT = (kv_end + BN - 1) / BN;
@@ -149,8 +167,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   auto stage_write = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      lds_write_b128(KR + buf * BTILE + st_r[i], kst[i]);
-      lds_write_b128(KT + buf * BTILE + st_t[i], kst[i]);
+      lds_write_b128(KU + buf * BTILE + st_r[i], kst[i]);
       lds_write_b128(VR + buf * BTILE + st_r[i], vst[i]);
     }
   };
@@ -164,6 +181,10 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   stage_load(0);
   stage_write(0);
 #pragma unroll
+  for (int ks = 0; ks < BKS; ++ks)  // Q~ = round(c.Q): the very operand the forward multiplied (fa_mfma_kernel.hip)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[ks][j] = (elem)((float)qf[ks][j] * c2);
+#pragma unroll
   for (int ks = 0; ks < BKS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));  // retire the prologue loads
   __syncthreads();
 
@@ -171,18 +192,27 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
     const int buf = t & 1, kv0 = t * BN;
     if (t + 1 < nT) stage_load(t + 1);
     if (!CAUSAL || kv0 <= qw0 + WM - 1) {
-      const lds_char *Kr = KR + buf * BTILE, *Kt = KT + buf * BTILE, *Vr = VR + buf * BTILE;
+      const lds_char *Kr = KU + buf * BTILE, *Kt = Kr, *Vr = VR + buf * BTILE;
       f32x16 s[2], dp[2];
+      __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
+      {
+        // 4 BKS row fragments (K and V alternating), each read LA products ahead of the MFMA that consumes it
+        constexpr int NF = 4 * BKS, LA = 4;
+        vec8 fr[NF];
+        auto fread = [&](int f) {  // f = (kb, ks, which): which 0 = K row fragment, 1 = V row fragment
+          const int kb = f / (2 * BKS), ks = (f / 2) % BKS;
+          fr[f] = __builtin_bit_cast(vec8, lds_read_b128(((f & 1) ? Vr : Kr) + kb * 32 * BRB + koff[ks]));
+        };
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
+        for (int f = 0; f < LA; ++f) fread(f);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[kb][i] = 0.0f; dp[kb][i] = 0.0f; }
-#pragma unroll
-        for (int ks = 0; ks < BKS; ++ks) {
-          const vec8 a = __builtin_bit_cast(vec8, lds_read_b128(Kr + kb * 32 * BRB + koff[ks]));
-          s[kb] = M::mfma(a, qf[ks], s[kb]);
-          const vec8 b = __builtin_bit_cast(vec8, lds_read_b128(Vr + kb * 32 * BRB + koff[ks]));
-          dp[kb] = M::mfma(b, dof[ks], dp[kb]);
+        for (int f = 0; f < NF; ++f) {
+          const int kb = f / (2 * BKS), ks = (f / 2) % BKS;
+          if (f & 1) dp[kb] = M::mfma(fr[f], dof[ks], ks == 0 ? ndlt : dp[kb]);
+          else s[kb] = M::mfma(fr[f], qf[ks], ks == 0 ? nlse : s[kb]);
+          if (f + LA < NF) fread(f + LA);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if (CAUSAL && (kv0 + BN - 1 > qw0)) {  // key > query -> masked (kernels.metal:748)
@@ -193,27 +223,41 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
           for (int i = 0; i < 16; ++i) s[kb][i] = ((i & 3) + 8 * (i >> 2) > lim) ? -INFINITY : s[kb][i];
         }
       }
-      // dS^T = (P^T * scale) o (dP^T - delta): keys in the registers, the query on the lane
+      // dQ^T += K^T.dS^T : step j = (kb, st, db); the transposed K fragments are read LA2 steps ahead of their MFMA, the first
+      // ones before the dS arithmetic (they do not depend on it)
+      {
+        constexpr int NJ = 4 * BDB, LA2 = 4, TV = BD == 64 ? 4 : 2;
+        s16x4 tlo[NJ], thi[NJ];
+        auto tread = [&](int j) {
+          const int R0 = 32 * (j / (2 * BDB)) + 16 * ((j / BDB) % 2), db = j % BDB;
+          tlo[j] = lds_read_tr16(Kt + R0 * BRB + voff[(R0 >> 3) % TV][db]);
+          thi[j] = lds_read_tr16(Kt + (R0 + 8) * BRB + voff[((R0 >> 3) + 1) % TV][db]);
+        };
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int j = 0; j < LA2; ++j) tread(j);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(0);
+        // dS^T = P^T o (dP^T - delta) (the softmax scale goes onto the finished dQ): keys in the registers, the query on the lane
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          s[kb][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c2, -lse2)) * (dp[kb][i] - dlt);
-      // dQ^T += K^T.dS^T
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+          for (int i = 0; i < 16; ++i) s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]) * dp[kb][i];
+        vec8 df[2][2];
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          vec8 df;
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) df[j] = (elem)s[kb][8 * st + j];
+          for (int st = 0; st < 2; ++st)
 #pragma unroll
-          for (int db = 0; db < BDB; ++db) {
-            const lds_char *kb_ = Kt + (32 * kb + 16 * st) * BRB + voff[db];
-            const s16x8 k8 = __builtin_shufflevector(lds_read_tr16(kb_), lds_read_tr16(kb_ + 8 * BRB), 0, 1, 2, 3, 4, 5, 6, 7);
-            dqacc[db] = M::mfma(__builtin_bit_cast(vec8, k8), df, dqacc[db]);
-          }
+            for (int j = 0; j < 8; ++j) df[kb][st][j] = (elem)s[kb][8 * st + j];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const s16x8 k8 = __builtin_shufflevector(tlo[j], thi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+          dqacc[j % BDB] = M::mfma(__builtin_bit_cast(vec8, k8), df[j / (2 * BDB)][(j / BDB) % 2], dqacc[j % BDB]);
+          if (j + LA2 < NJ) tread(j + LA2);
+          __builtin_amdgcn_sched_barrier(0);
         }
+      }
     }
     if (t + 1 < nT) stage_write(buf ^ 1);
     __syncthreads();
@@ -225,7 +269,8 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
     for (int db = 0; db < BDB; ++db)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        const float4 w = make_float4(dqacc[db][4 * g4], dqacc[db][4 * g4 + 1], dqacc[db][4 * g4 + 2], dqacc[db][4 * g4 + 3]);
+        const float4 w = make_float4(dqacc[db][4 * g4] * p.scale, dqacc[db][4 * g4 + 1] * p.scale, dqacc[db][4 * g4 + 2] * p.scale,
+                                     dqacc[db][4 * g4 + 3] * p.scale);
         *reinterpret_cast<float4 *>(dq + 32 * db + 8 * g4 + 4 * h) = w;
       }
   }
@@ -242,11 +287,9 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
   using elem = typename M::elem;
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
-  lds_char *QR = smem;                // [2] Q tile (64 rows), row-read image
-  lds_char *QT = smem + 2 * BTILE;    // [2] Q tile, transposed-read image
-  lds_char *OR_ = smem + 4 * BTILE;   // [2] dO tile, row-read image
-  lds_char *OT = smem + 6 * BTILE;    // [2] dO tile, transposed-read image
-  lds_char *ROWS = smem + 8 * BTILE;  // [2][2][64] floats: lse*log2e, delta*scale of the tile's query rows
+  lds_char *QU = smem;                // [2] Q tile (64 rows): read by rows for S, transposed for dK
+  lds_char *OU = smem + 2 * BTILE;    // [2] dO tile: read by rows for dP, transposed for dV
+  lds_char *ROWS = smem + 4 * BTILE;  // [2][2][64] floats: -lse*log2e, -delta of the tile's query rows (the chains' initial accumulators)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -271,30 +314,34 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
   }
   const float c2 = p.scale * LOG2E;
 
-  const int kx = row_swz(r);
+  const int kx = u_swz(r);
   int koff[BKS];
 #pragma unroll
   for (int ks = 0; ks < BKS; ++ks) koff[ks] = r * BRB + (((2 * ks + h) ^ kx) << 4);
   const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
-  const int vx = tr_swz(vq);
-  int voff[BDB];
+  int voff[NTV][BDB];
 #pragma unroll
-  for (int db = 0; db < BDB; ++db) voff[db] = (4 * h + vq) * BRB + ((((4 * db) ^ vx) + 2 * g1 + (vp >> 1)) << 4) + 8 * (vp & 1);
+  for (int tv = 0; tv < NTV; ++tv)
+#pragma unroll
+    for (int db = 0; db < BDB; ++db) voff[tv][db] = tr_off(tv, db, h, g1, vq, vp);
   constexpr int NCH = BN * BCPR / NTHREADS;
-  int st_g[NCH], st_r[NCH], st_t[NCH];
+  int st_g[NCH], st_r[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = tid + i * NTHREADS, row = c / BCPR, ch = c % BCPR;
     st_g[i] = row * BRB + ch * 16;
-    st_r[i] = row * BRB + ((ch ^ row_swz(row)) << 4);
-    st_t[i] = row * BRB + ((ch ^ tr_swz(row)) << 4);
+    st_r[i] = row * BRB + ((ch ^ u_swz(row)) << 4);
   }
   // query tiles of 64 rows; under the causal mask only tiles that reach this block's first key
   const int nTq = (p.N + BN - 1) / BN;
   const int t_begin = CAUSAL ? k0 / BN : 0;
 
   u32x4 qst[NCH], ost[NCH];
-  float rowv = 0.0f;  // threads 0..63: lse*log2e of row tid; 64..127: delta*scale of row tid-64
+  // threads 0..63: lse of row tid of the next tile; 64..127: delta of row tid-64. The RAW loaded value: any arithmetic on it
+  // here makes hipcc wait for it -- vmcnt(0), i.e. for the whole tile's loads issued just before -- at the top of every
+  // iteration (seen in the ISA: the memory latency was exposed once per tile). It is scaled / negated in stage_write.
+  float rowv = 0.0f;
+  const float *row_src = (tid < 64 ? p.lse : p.delta) + (long long)bh * p.N;
   auto stage_load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -303,19 +350,20 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
     }
     if (tid < 128) {
       const int qi = t * BN + (tid & 63);
-      if (tid < 64) rowv = qi < p.N ? p.lse[(long long)bh * p.N + qi] * LOG2E : INFINITY;  // p = 0 past N
-      else rowv = qi < p.N ? p.delta[(long long)bh * p.N + qi] * p.scale : 0.0f;  // delta*scale: dS = P*fma(dP, scale, -delta*scale)
+      rowv = row_src[qi < p.N ? qi : p.N - 1];
     }
   };
-  auto stage_write = [&](int buf) {
+  auto stage_write = [&](int buf, int wt) {  // wt = the tile the staged registers hold
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      lds_write_b128(QR + buf * BTILE + st_r[i], qst[i]);
-      lds_write_b128(QT + buf * BTILE + st_t[i], qst[i]);
-      lds_write_b128(OR_ + buf * BTILE + st_r[i], ost[i]);
-      lds_write_b128(OT + buf * BTILE + st_t[i], ost[i]);
+      lds_write_b128(QU + buf * BTILE + st_r[i], qst[i]);
+      lds_write_b128(OU + buf * BTILE + st_r[i], ost[i]);
     }
-    if (tid < 128) lds_write_b32(ROWS + buf * 512 + tid * 4, __builtin_bit_cast(unsigned, rowv));
+    if (tid < 128) {  // (stage_write(buf) holds tile t_of_write: its rows past N get p = 0 through -inf)
+      const int qi = wt * BN + (tid & 63);
+      const float v = (tid < 64) ? (qi < p.N ? -rowv * LOG2E : -INFINITY) : (qi < p.N ? -rowv : 0.0f);
+      lds_write_b32(ROWS + buf * 512 + tid * 4, __builtin_bit_cast(unsigned, v));
+    }
   };
 
   f32x16 dkacc[BDB], dvacc[BDB];
@@ -326,8 +374,12 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
 
   if (t_begin < nTq) {
     stage_load(t_begin);
-    stage_write(0);
+    stage_write(0, t_begin);
   }
+#pragma unroll
+  for (int ks = 0; ks < BKS; ++ks)  // K~ = round(c.K): S' = Q.K~ comes out in log2 units
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kf[ks][j] = (elem)((float)kf[ks][j] * c2);
 #pragma unroll
   for (int ks = 0; ks < BKS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
   __syncthreads();
@@ -336,21 +388,60 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
     const int buf = (t - t_begin) & 1, qt0 = t * BN;
     if (t + 1 < nTq) stage_load(t + 1);
     if (!CAUSAL || qt0 + BN - 1 >= kw0) {  // some query of the tile sees this wave's first key
-      const lds_char *Qr = QR + buf * BTILE, *Qt = QT + buf * BTILE, *Or = OR_ + buf * BTILE, *Ot = OT + buf * BTILE;
+      const lds_char *Qr = QU + buf * BTILE, *Qt = Qr, *Or = OU + buf * BTILE, *Ot = Or;
       const lds_char *rows = ROWS + buf * 512;
       f32x16 s[2], dp[2];
+      __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
+      // the chains start from the row constants: registers 4g..4g+3 of block qb are query rows 32qb + 8g + 4h + 0..3 of the tile
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[qb][i] = 0.0f; dp[qb][i] = 0.0f; }
+        for (int g = 0; g < 4; ++g) {
+          const int ql = 32 * qb + 8 * g + 4 * h;
+          const u32x4 l4 = lds_read_b128(rows + ql * 4);
+          const u32x4 d4 = lds_read_b128(rows + 256 + ql * 4);
 #pragma unroll
-        for (int ks = 0; ks < BKS; ++ks) {
-          const vec8 a = __builtin_bit_cast(vec8, lds_read_b128(Qr + qb * 32 * BRB + koff[ks]));
-          s[qb] = M::mfma(a, kf[ks], s[qb]);
-          const vec8 b = __builtin_bit_cast(vec8, lds_read_b128(Or + qb * 32 * BRB + koff[ks]));
-          dp[qb] = M::mfma(b, vf[ks], dp[qb]);
+          for (int e = 0; e < 4; ++e) {
+            // (scalar temporaries on purpose: __builtin_bit_cast applied directly to the vector element expression
+            //  l4[e] read element 0 for every e -- seen in the IR)
+            const unsigned lw = l4[e], dw = d4[e];
+            s[qb][4 * g + e] = __builtin_bit_cast(float, lw);
+            dp[qb][4 * g + e] = __builtin_bit_cast(float, dw);
+          }
+        }
+      {
+        constexpr int NF = 4 * BKS, LA = 4;
+        vec8 fr[NF];
+        auto fread = [&](int f) {  // f = (qb, ks, which): which 0 = Q row fragment, 1 = dO row fragment
+          const int qb = f / (2 * BKS), ks = (f / 2) % BKS;
+          fr[f] = __builtin_bit_cast(vec8, lds_read_b128(((f & 1) ? Or : Qr) + qb * 32 * BRB + koff[ks]));
+        };
+#pragma unroll
+        for (int f = 0; f < LA; ++f) fread(f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int qb = f / (2 * BKS), ks = (f / 2) % BKS;
+          if (f & 1) dp[qb] = M::mfma(fr[f], vf[ks], dp[qb]);
+          else s[qb] = M::mfma(fr[f], kf[ks], s[qb]);
+          if (f + LA < NF) fread(f + LA);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
+      // dV / dK fragments (step j = (qb, st, db, which): which 0 = dO^T fragment -> dV, 1 = Q^T fragment -> dK) are read LA2
+      // steps ahead of their MFMA, the first ones before the P / dS arithmetic (they do not depend on it)
+      constexpr int NJ = 8 * BDB, LA2 = 4, TV = BD == 64 ? 4 : 2;
+      s16x4 tlo[NJ], thi[NJ];
+      auto tread = [&](int j) {
+        const int jj = j / 2, R0 = 32 * (jj / (2 * BDB)) + 16 * ((jj / BDB) % 2), db = jj % BDB;
+        const lds_char *src = (j & 1) ? Qt : Ot;
+        tlo[j] = lds_read_tr16(src + R0 * BRB + voff[(R0 >> 3) % TV][db]);
+        thi[j] = lds_read_tr16(src + (R0 + 8) * BRB + voff[((R0 >> 3) + 1) % TV][db]);
+      };
+#pragma unroll
+      for (int j = 0; j < LA2; ++j) tread(j);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
       // registers 4g..4g+3 of block qb are query rows 32qb + 8g + 4h + 0..3 of the tile
       vec8 pf[2][2], df[2][2];
       // only tiles that cross the diagonal for this wave need the per-element mask (wave-uniform)
@@ -360,19 +451,13 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int ql = 32 * qb + 8 * g + 4 * h;
-          const u32x4 l4 = lds_read_b128(rows + ql * 4);
-          const u32x4 d4 = lds_read_b128(rows + 256 + ql * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int i = 4 * g + e;
-            // (scalar temporaries on purpose: __builtin_bit_cast applied directly to the vector
-            //  element expression l4[e] read element 0 for every e -- seen in the IR)
-            const unsigned lw = l4[e], dw = d4[e];
-            const float lse_q = __builtin_bit_cast(float, lw), delta_q = __builtin_bit_cast(float, dw);
-            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][i], c2, -lse_q));
+            float pv = __builtin_amdgcn_exp2f(s[qb][i]);  // S' = Q.K~ - lse*log2e came out of the matrix core
             if (need_mask && (qt0 + ql + e < krow)) pv = 0.0f;  // key > query (kernels.metal:748)
             s[qb][i] = pv;
-            dp[qb][i] = pv * __builtin_fmaf(dp[qb][i], p.scale, -delta_q);  // delta_q already carries scale
+            dp[qb][i] = pv * dp[qb][i];  // dS (without the softmax scale: it goes onto the finished dK)
           }
         }
 #pragma unroll
@@ -384,20 +469,20 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
           }
       }
       // dV^T += dO^T.P ; dK^T += Q^T.dS   (reduction over the tile's 64 query rows)
+      __builtin_amdgcn_s_setprio(1);
+      {
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-          for (int db = 0; db < BDB; ++db) {
-            const int roff = (32 * qb + 16 * st) * BRB + voff[db];
-            const s16x8 o8 = __builtin_shufflevector(lds_read_tr16(Ot + roff), lds_read_tr16(Ot + roff + 8 * BRB), 0, 1, 2, 3, 4, 5, 6, 7);
-            dvacc[db] = M::mfma(__builtin_bit_cast(vec8, o8), pf[qb][st], dvacc[db]);
-            const s16x8 q8 = __builtin_shufflevector(lds_read_tr16(Qt + roff), lds_read_tr16(Qt + roff + 8 * BRB), 0, 1, 2, 3, 4, 5, 6, 7);
-            dkacc[db] = M::mfma(__builtin_bit_cast(vec8, q8), df[qb][st], dkacc[db]);
-          }
+        for (int j = 0; j < NJ; ++j) {
+          const int jj = j / 2, qb = jj / (2 * BDB), st = (jj / BDB) % 2, db = jj % BDB;
+          const s16x8 a8 = __builtin_shufflevector(tlo[j], thi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+          if (j & 1) dkacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), df[qb][st], dkacc[db]);
+          else dvacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), pf[qb][st], dvacc[db]);
+          if (j + LA2 < NJ) tread(j + LA2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
-    if (t + 1 < nTq) stage_write(buf ^ 1);
+    if (t + 1 < nTq) stage_write(buf ^ 1, t + 1);
     __syncthreads();
   }
   if (krow < p.N) {
@@ -407,7 +492,8 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d0 = 32 * db + 8 * g4 + 4 * h;
-        *reinterpret_cast<float4 *>(dk + d0) = make_float4(dkacc[db][4 * g4], dkacc[db][4 * g4 + 1], dkacc[db][4 * g4 + 2], dkacc[db][4 * g4 + 3]);
+        *reinterpret_cast<float4 *>(dk + d0) = make_float4(dkacc[db][4 * g4] * p.scale, dkacc[db][4 * g4 + 1] * p.scale, dkacc[db][4 * g4 + 2] * p.scale,
+                                                             dkacc[db][4 * g4 + 3] * p.scale);
         *reinterpret_cast<float4 *>(dv + d0) = make_float4(dvacc[db][4 * g4], dvacc[db][4 * g4 + 1], dvacc[db][4 * g4 + 2], dvacc[db][4 * g4 + 3]);
       }
   }
@@ -423,7 +509,7 @@ static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
   const long long rows = (long long)p.B * p.H * p.N;
   constexpr int RPB = 256 / (D / 8);
   const int nB = (p.N + BM - 1) / BM;
-  const size_t smem_dq = 6 * BTILE, smem_kv = 8 * BTILE + 1024;
+  const size_t smem_dq = 4 * BTILE, smem_kv = 4 * BTILE + 1024;
   auto kq = bwd_dq_kernel<Tag, D, CAUSAL>;
   auto kk = bwd_dkdv_kernel<Tag, D, CAUSAL>;
   hipError_t e = set_dyn_lds_once((const void *)kk, (int)smem_kv);

@@ -20,15 +20,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("outdir"); ap.add_argument("shape", nargs="+")
 ap.add_argument("--iters", type=int, default=6); ap.add_argument("--match", default="fwd_")
 ap.add_argument("--sets", default="sq1,sq2")
+ap.add_argument("--script", default="run_shape.py", help="program under tools/ to profile (run_bwd.py: shape = B H N dtype causal)")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(a.outdir, exist_ok=True)
-shape = a.shape[:6] + [str(a.iters)] + a.shape[6:]
+nshape = 5 if a.script == "run_bwd.py" else 6
+shape = a.shape[:nshape] + [str(a.iters)] + a.shape[nshape:]
 res = {}
 for name in a.sets.split(","):
     d = os.path.join(a.outdir, name)
     cmd = ["rocprofv3", "--pmc"] + SETS[name] + ["-d", d, "--output-format", "csv", "--", sys.executable,
-                                                 os.path.join(root, "tools", "run_shape.py")] + shape
+                                                 os.path.join(root, "tools", a.script)] + shape
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     open(os.path.join(a.outdir, name + ".log"), "w").write(r.stdout)
