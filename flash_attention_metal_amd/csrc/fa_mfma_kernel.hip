@@ -44,6 +44,12 @@
 #ifndef FA_VPRE_HALF
 #define FA_VPRE_HALF 1  // 1: only the first 32 keys' V^T fragments are prefetched under the QK^T MFMAs, the second half under the first half's PV MFMAs (-16 live registers)
 #endif
+#ifndef FA_LAK
+#define FA_LAK 2  // head dims other than 64: K fragments are read this many MFMAs ahead of their use
+#endif
+#ifndef FA_LAV
+#define FA_LAV 2  // ... and V^T fragments
+#endif
 #ifndef FA_PRIO
 #define FA_PRIO 2  // wave priority: 2 = raised around the MFMA clusters (+0.4..0.9 % A/B), 1 = around the softmax (-1..-6 %), 0 = off
 #endif
@@ -387,7 +393,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
       } else {
         // head_dim 128: 16 K fragments would cost 64 VGPRs if held live; read each one LA MFMAs ahead of
         // its use instead (profile before: 9 % of wave time stalled on LDS issue, 14 % MFMA/VALU co-execution)
-        constexpr int NK = 2 * KS, LA = 2;
+        constexpr int NK = 2 * KS, LA = FA_LAK;
         vec8 kf[NK];
         auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(kptr[i % KS] + buf * KTILE + (i / KS) * 32 * RB)); };
 #pragma unroll
@@ -531,7 +537,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
         }
       } else {
         // V^T fragments just in time, LA MFMAs ahead (step j = (kb, st, db))
-        constexpr int NV = 2 * 2 * DB, LA = 2;
+        constexpr int NV = 2 * 2 * DB, LA = FA_LAV;
         s16x4 wlo[NV], whi[NV];
         auto vread = [&](int j) {
           const lds_char *vb = vptr[j % DB] + buf * TILE + (32 * (j / (2 * DB)) + 16 * ((j / DB) % 2)) * RB;
