@@ -6,8 +6,9 @@
 // dQ += dS K, dK += dS^T Q -- nothing else. The reference flushes dK/dV with global float
 // atomics from every Q block (:1221-1246); here no gradient is accumulated across workgroups:
 //
-//   bwd_delta_kernel   delta[b,h,i] = sum_d dO*O                       (workspace, B*H*N floats)
 //   bwd_dq_kernel      one workgroup per 128 query rows, loops over KV tiles (like the forward):
+//                        delta[b,h,i] = sum_d dO*O of its rows, formed in the prologue from the dO fragments it holds
+//                        anyway and left in the workspace (B*H*N floats) for the dK/dV kernel (round 2: a kernel of its own),
 //                        S^T = K.Q^T, dP^T = V.dO^T, dS^T = P^T o (dP^T - delta) * scale,
 //                        dQ^T += K^T.dS^T
 //   bwd_dkdv_kernel    one workgroup per 128 keys, loops over Q tiles:
@@ -68,29 +69,6 @@ constexpr float LOG2E = 1.4426950408889634f;
   (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)u_swz; (void)tr_off; (void)NTV
 
 // ---------------------------------------------------------------------------
-template <typename elem, int D>
-__global__ __launch_bounds__(256) void bwd_delta_kernel(BwdParams p) {
-  // D/8 lanes per row, 16 bytes each; 256 / (D/8) rows per block
-  constexpr int LPR = D / 8, RPB = 256 / LPR;
-  const int tid = threadIdx.x;
-  const long long row = (long long)blockIdx.x * RPB + (tid / LPR);
-  const long long rows = (long long)p.B * p.H * p.N;
-  float acc = 0.0f;
-  if (row < rows) {
-    const long long bh = row / p.N, i = row % p.N;
-    const long long off = (bh / p.H) * p.batch_stride + (bh % p.H) * p.head_stride + i * D + (tid % LPR) * 8;
-    typedef elem e8 __attribute__((ext_vector_type(8)));
-    const e8 a = *reinterpret_cast<const e8 *>((const elem *)p.o + off);
-    const e8 b = *reinterpret_cast<const e8 *>((const elem *)p.d_o + off);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)b[j];
-  }
-#pragma unroll
-  for (int sft = 1; sft < LPR; sft <<= 1) acc += __shfl_xor(acc, sft);
-  if (row < rows && (tid % LPR) == 0) p.delta[row] = acc;
-}
-
-// ---------------------------------------------------------------------------
 // dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
 // ---------------------------------------------------------------------------
 template <typename Tag, int D, bool CAUSAL>
@@ -128,8 +106,23 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   // S' = K.Q~ - lse*log2e straight out of the matrix core (rows past N: -inf, p = 0); dP' = V.dO - delta likewise
   const bool qvalid = qrow < p.N;
   const float lse2 = qvalid ? p.lse[(long long)bh * p.N + qrow] * LOG2E : INFINITY;
-  const float dlt = qvalid ? p.delta[(long long)bh * p.N + qrow] : 0.0f;
   const float c2 = p.scale * LOG2E;
+  // delta_i = rowsum(dO o O) (kernels.metal:983-990): this lane holds half of row i's dO (columns 16ks + 8h ..), loads the
+  // same half of O, and the two halves of the row meet through one permlane swap; written once for the dK/dV kernel
+  float dlt = 0.0f;
+  {
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.o + base), 0, head_bytes, 0x00020000);
+#pragma unroll
+    for (int ks = 0; ks < BKS; ++ks) {
+      const vec8 of = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(ro, (unsigned)qrow * BRB + (2 * ks + h) * 16, 0, 0));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dlt = __builtin_fmaf((float)of[j], (float)dof[ks][j], dlt);
+    }
+    float lo, hi;
+    half_pair(dlt, lo, hi);
+    dlt = lo + hi;
+    if (qvalid && h == 0) p.delta[(long long)bh * p.N + qrow] = dlt;
+  }
   f32x16 nlse, ndlt;  // the row constants, one per lane, in all 16 registers of a tuple: C operands of the chains' first MFMAs
 #pragma unroll
   for (int i = 0; i < 16; ++i) { nlse[i] = -lse2; ndlt[i] = -dlt; }
@@ -504,10 +497,7 @@ bool bwd_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype ==
 
 template <typename Tag, int D, bool CAUSAL>
 static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
-  using elem = typename MT<Tag>::elem;
   constexpr int BTILE = BN * D * 2;
-  const long long rows = (long long)p.B * p.H * p.N;
-  constexpr int RPB = 256 / (D / 8);
   const int nB = (p.N + BM - 1) / BM;
   const size_t smem_dq = 4 * BTILE, smem_kv = 4 * BTILE + 1024;
   auto kq = bwd_dq_kernel<Tag, D, CAUSAL>;
@@ -519,7 +509,6 @@ static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
     if (e != hipSuccess) return e;
   }
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
-  hipLaunchKernelGGL((bwd_delta_kernel<elem, D>), dim3((unsigned)((rows + RPB - 1) / RPB)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(kq, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
   hipLaunchKernelGGL(kk, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_kv, s, p);
   return hipGetLastError();

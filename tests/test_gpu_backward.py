@@ -38,8 +38,9 @@ def grads(fa, q, k, v, do, dtype, causal):
 
 def rel(a, ref):
     # relative to the largest reference gradient; a gradient that is exactly zero in exact arithmetic (a single
-    # key: P = 1, dS = 0) may carry 1e-9 of fp32 rounding, hence the absolute floor
-    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-5)
+    # key: P = 1, dS = P (dP - delta) = 0) carries the fp32 rounding of dP (matrix core) against delta (FMA chain in
+    # the dQ kernel's prologue): a few 1e-8 on values of order 1, hence the absolute floor
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-4)
 
 
 @pytest.mark.parametrize("D", [64, 128])
@@ -64,7 +65,9 @@ def test_backward_known_answers(fa, oracle_mod):
     q, k, v = make_qkv(oracle_mod, 1, 2, N, 64, "bf16")
     do = oracle_mod.round_to(oracle_mod.init_random(2 * N * 64, 45).reshape(1, 2, N, 64), "bf16")
     dq, dk, dv = grads(fa, q, k, v, do, "bf16", True)
-    assert np.count_nonzero(dq[:, :, 0]) == 0
+    # (zero up to the fp32 rounding of dP - delta: delta enters the dP chain as its initial accumulator, so the two equal sums
+    #  are formed in different orders; round 2 subtracted them after the fact and happened to cancel exactly)
+    assert np.abs(dq[:, :, 0]).max() < 1e-6
     # V = const: O = const, dP_ij = dO_i . v is the same for every j -> dS = 0 -> dQ = dK = 0 up to rounding
     vc = np.full_like(v, 0.5)
     dq, dk, dv = grads(fa, q, k, vc, do, "bf16", False)
