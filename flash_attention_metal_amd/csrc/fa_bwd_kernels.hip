@@ -48,6 +48,12 @@ struct BwdParams {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+#ifndef FA_BWD_SUB
+#define FA_BWD_SUB 2  // 64-row sub-tiles per staged tile: one barrier and one staging pass per FA_BWD_SUB * 64 keys (dQ) / queries (dK, dV)
+#endif
+constexpr int BSUB = FA_BWD_SUB;
+constexpr int BT = BSUB * BN;  // rows of a staged tile
+
 // per-head-dim constants of the kernels below (the reference kernel is head_dim 64 only, kernels.metal:905-1265;
 // 128 is the same algorithm with twice the k-steps / output blocks and one workgroup per CU)
 #define FA_BWD_CONSTS(D)                                                                         \
@@ -56,7 +62,8 @@ constexpr float LOG2E = 1.4426950408889634f;
   constexpr int BCPR = BD / 8;     /* 16-byte chunks per row */                                  \
   constexpr int BKS = BD / 16;     /* k-steps over the head dim */                               \
   constexpr int BDB = BD / 32;     /* 32-wide output blocks over the head dim */                 \
-  constexpr int BTILE = BN * BRB;  /* one 64-row tile image */                                   \
+  constexpr int BTILE = BN * BRB;  /* one 64-row sub-tile image */                               \
+  constexpr int STILE = BSUB * BTILE; /* one staged tile (BT rows) */                             \
   /* XOR on the 16-byte chunk index of a row: conflict-free for ds_read_b128 row reads, ds_read_b64_tr_b16 and ds_write_b128 */ \
   auto u_swz = [](int row) { return BD == 64 ? ((((row >> 1) & 1) << 2) | ((row >> 3) & 3)) : (((row & 3) << 2) | ((row >> 2) & 3)); }; \
   /* transposed read of the 4-row x 32-column block (R0 + 4h + vq, columns 32db ..), R0 a multiple of 8: the swizzle's low   */ \
@@ -66,7 +73,7 @@ constexpr float LOG2E = 1.4426950408889634f;
     const int row = 8 * variant + 4 * h_ + vq_; /* a representative R0 = 8 * variant */        \
     return (4 * h_ + vq_) * BRB + ((((4 * db) + 2 * g1_ + (vp_ >> 1)) ^ u_swz(row)) << 4) + 8 * (vp_ & 1); \
   };                                                                                          \
-  (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)u_swz; (void)tr_off; (void)NTV
+  (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)STILE; (void)u_swz; (void)tr_off; (void)NTV
 
 // ---------------------------------------------------------------------------
 // dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
@@ -79,8 +86,8 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   using elem = typename M::elem;
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
-  lds_char *KU = smem;               // [2] K tile (read by rows for S, transposed for dQ)
-  lds_char *VR = smem + 2 * BTILE;   // [2] V tile (read by rows)
+  lds_char *KU = smem;               // [2] K tile of BT rows (read by rows for S, transposed for dQ)
+  lds_char *VR = smem + 2 * STILE;   // [2] V tile (read by rows)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   for (int tv = 0; tv < NTV; ++tv)
 #pragma unroll
     for (int db = 0; db < BDB; ++db) voff[tv][db] = tr_off(tv, db, h, g1, vq, vp);
-  constexpr int NCH = BN * BCPR / NTHREADS;  // 2
+  constexpr int NCH = BT * BCPR / NTHREADS;
   int st_g[NCH], st_r[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -147,21 +154,21 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
     st_r[i] = row * BRB + ((ch ^ u_swz(row)) << 4);
   }
   const int kv_end = CAUSAL ? min(p.N, q0 + BM) : p.N;
-  const int nT = (kv_end + BN - 1) / BN;
+  const int nT = (kv_end + BT - 1) / BT;
 
   u32x4 kst[NCH], vst[NCH];
   auto stage_load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)t * BTILE + st_g[i], 0, 0);
-      vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)t * BTILE + st_g[i], 0, 0);
+      kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)t * STILE + st_g[i], 0, 0);
+      vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)t * STILE + st_g[i], 0, 0);
     }
   };
   auto stage_write = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      lds_write_b128(KU + buf * BTILE + st_r[i], kst[i]);
-      lds_write_b128(VR + buf * BTILE + st_r[i], vst[i]);
+      lds_write_b128(KU + buf * STILE + st_r[i], kst[i]);
+      lds_write_b128(VR + buf * STILE + st_r[i], vst[i]);
     }
   };
 
@@ -182,10 +189,13 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   __syncthreads();
 
   for (int t = 0; t < nT; ++t) {
-    const int buf = t & 1, kv0 = t * BN;
+    const int buf = t & 1;
     if (t + 1 < nT) stage_load(t + 1);
-    if (!CAUSAL || kv0 <= qw0 + WM - 1) {
-      const lds_char *Kr = KU + buf * BTILE, *Kt = Kr, *Vr = VR + buf * BTILE;
+#pragma unroll
+    for (int sub = 0; sub < BSUB; ++sub) {
+    const int kv0 = t * BT + sub * BN;
+    if (kv0 < kv_end && (!CAUSAL || kv0 <= qw0 + WM - 1)) {
+      const lds_char *Kr = KU + buf * STILE + sub * BTILE, *Kt = Kr, *Vr = VR + buf * STILE + sub * BTILE;
       f32x16 s[2], dp[2];
       __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
       {
@@ -252,6 +262,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
         }
       }
     }
+    }  // sub-tiles
     if (t + 1 < nT) stage_write(buf ^ 1);
     __syncthreads();
   }
@@ -280,9 +291,9 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
   using elem = typename M::elem;
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
-  lds_char *QU = smem;                // [2] Q tile (64 rows): read by rows for S, transposed for dK
-  lds_char *OU = smem + 2 * BTILE;    // [2] dO tile: read by rows for dP, transposed for dV
-  lds_char *ROWS = smem + 4 * BTILE;  // [2][2][64] floats: -lse*log2e, -delta of the tile's query rows (the chains' initial accumulators)
+  lds_char *QU = smem;                // [2] Q tile (BT rows): read by rows for S, transposed for dK
+  lds_char *OU = smem + 2 * STILE;    // [2] dO tile: read by rows for dP, transposed for dV
+  lds_char *ROWS = smem + 4 * STILE;  // [2][2][BT] floats: -lse*log2e, -delta of the tile's query rows (the chains' initial accumulators)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
   for (int tv = 0; tv < NTV; ++tv)
 #pragma unroll
     for (int db = 0; db < BDB; ++db) voff[tv][db] = tr_off(tv, db, h, g1, vq, vp);
-  constexpr int NCH = BN * BCPR / NTHREADS;
+  constexpr int NCH = BT * BCPR / NTHREADS;
   int st_g[NCH], st_r[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
@@ -325,37 +336,38 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
     st_g[i] = row * BRB + ch * 16;
     st_r[i] = row * BRB + ((ch ^ u_swz(row)) << 4);
   }
-  // query tiles of 64 rows; under the causal mask only tiles that reach this block's first key
-  const int nTq = (p.N + BN - 1) / BN;
-  const int t_begin = CAUSAL ? k0 / BN : 0;
+  // query tiles of BT rows; under the causal mask only tiles that reach this block's first key
+  const int nTq = (p.N + BT - 1) / BT;
+  const int t_begin = CAUSAL ? k0 / BT : 0;
+  static_assert(2 * BT <= NTHREADS, "one thread per staged row constant");
 
   u32x4 qst[NCH], ost[NCH];
-  // threads 0..63: lse of row tid of the next tile; 64..127: delta of row tid-64. The RAW loaded value: any arithmetic on it
+  // threads 0..BT-1: lse of row tid of the next tile; BT..2BT-1: delta of row tid-BT. The RAW loaded value: any arithmetic on it
   // here makes hipcc wait for it -- vmcnt(0), i.e. for the whole tile's loads issued just before -- at the top of every
   // iteration (seen in the ISA: the memory latency was exposed once per tile). It is scaled / negated in stage_write.
   float rowv = 0.0f;
-  const float *row_src = (tid < 64 ? p.lse : p.delta) + (long long)bh * p.N;
+  const float *row_src = (tid < BT ? p.lse : p.delta) + (long long)bh * p.N;
   auto stage_load = [&](int t) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      qst[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)t * BTILE + st_g[i], 0, 0);
-      ost[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)t * BTILE + st_g[i], 0, 0);
+      qst[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)t * STILE + st_g[i], 0, 0);
+      ost[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)t * STILE + st_g[i], 0, 0);
     }
-    if (tid < 128) {
-      const int qi = t * BN + (tid & 63);
+    if (tid < 2 * BT) {
+      const int qi = t * BT + (tid & (BT - 1));
       rowv = row_src[qi < p.N ? qi : p.N - 1];
     }
   };
   auto stage_write = [&](int buf, int wt) {  // wt = the tile the staged registers hold
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      lds_write_b128(QU + buf * BTILE + st_r[i], qst[i]);
-      lds_write_b128(OU + buf * BTILE + st_r[i], ost[i]);
+      lds_write_b128(QU + buf * STILE + st_r[i], qst[i]);
+      lds_write_b128(OU + buf * STILE + st_r[i], ost[i]);
     }
-    if (tid < 128) {  // (stage_write(buf) holds tile t_of_write: its rows past N get p = 0 through -inf)
-      const int qi = wt * BN + (tid & 63);
-      const float v = (tid < 64) ? (qi < p.N ? -rowv * LOG2E : -INFINITY) : (qi < p.N ? -rowv : 0.0f);
-      lds_write_b32(ROWS + buf * 512 + tid * 4, __builtin_bit_cast(unsigned, v));
+    if (tid < 2 * BT) {  // (the staged registers hold tile wt: its rows past N get p = 0 through -inf)
+      const int qi = wt * BT + (tid & (BT - 1));
+      const float v = (tid < BT) ? (qi < p.N ? -rowv * LOG2E : -INFINITY) : (qi < p.N ? -rowv : 0.0f);
+      lds_write_b32(ROWS + buf * (2 * BT * 4) + tid * 4, __builtin_bit_cast(unsigned, v));
     }
   };
 
@@ -378,11 +390,14 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
   __syncthreads();
 
   for (int t = t_begin; t < nTq; ++t) {
-    const int buf = (t - t_begin) & 1, qt0 = t * BN;
+    const int buf = (t - t_begin) & 1;
     if (t + 1 < nTq) stage_load(t + 1);
-    if (!CAUSAL || qt0 + BN - 1 >= kw0) {  // some query of the tile sees this wave's first key
-      const lds_char *Qr = QU + buf * BTILE, *Qt = Qr, *Or = OU + buf * BTILE, *Ot = Or;
-      const lds_char *rows = ROWS + buf * 512;
+#pragma unroll
+    for (int sub = 0; sub < BSUB; ++sub) {
+    const int qt0 = t * BT + sub * BN;
+    if (qt0 < p.N && (!CAUSAL || qt0 + BN - 1 >= kw0)) {  // some query of the sub-tile sees this wave's first key
+      const lds_char *Qr = QU + buf * STILE + sub * BTILE, *Qt = Qr, *Or = OU + buf * STILE + sub * BTILE, *Ot = Or;
+      const lds_char *rows = ROWS + buf * (2 * BT * 4) + sub * (BN * 4);
       f32x16 s[2], dp[2];
       __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
       // the chains start from the row constants: registers 4g..4g+3 of block qb are query rows 32qb + 8g + 4h + 0..3 of the tile
@@ -392,7 +407,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
         for (int g = 0; g < 4; ++g) {
           const int ql = 32 * qb + 8 * g + 4 * h;
           const u32x4 l4 = lds_read_b128(rows + ql * 4);
-          const u32x4 d4 = lds_read_b128(rows + 256 + ql * 4);
+          const u32x4 d4 = lds_read_b128(rows + BT * 4 + ql * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // (scalar temporaries on purpose: __builtin_bit_cast applied directly to the vector element expression
@@ -475,6 +490,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
         }
       }
     }
+    }  // sub-tiles
     if (t + 1 < nTq) stage_write(buf ^ 1, t + 1);
     __syncthreads();
   }
@@ -499,10 +515,11 @@ template <typename Tag, int D, bool CAUSAL>
 static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
   constexpr int BTILE = BN * D * 2;
   const int nB = (p.N + BM - 1) / BM;
-  const size_t smem_dq = 4 * BTILE, smem_kv = 4 * BTILE + 1024;
+  const size_t smem_dq = 4 * BSUB * BTILE, smem_kv = 4 * BSUB * BTILE + 2 * 2 * BT * 4;
   auto kq = bwd_dq_kernel<Tag, D, CAUSAL>;
   auto kk = bwd_dkdv_kernel<Tag, D, CAUSAL>;
-  hipError_t e = set_dyn_lds_once((const void *)kk, (int)smem_kv);
+  hipError_t e = hipSuccess;
+  if (smem_kv > 48 * 1024) e = set_dyn_lds_once((const void *)kk, (int)smem_kv);
   if (e != hipSuccess) return e;
   if (smem_dq > 48 * 1024) {
     e = set_dyn_lds_once((const void *)kq, (int)smem_dq);
