@@ -35,6 +35,7 @@ const char *fa_variant_name(int v) {
     case FA_VARIANT_MFMA_SPLITKV: return "mfma_splitkv";
     case FA_VARIANT_MFMA_SPLIT2: return "mfma_split2";
     case FA_VARIANT_MFMA_EXACT: return "mfma_exact";
+    case FA_VARIANT_MFMA_H64S2: return "mfma_h64s2";
     default: return "?";
   }
 }
@@ -68,6 +69,7 @@ int fa_supported(int dtype, int variant, int D) {
     case FA_VARIANT_MFMA_SPLITKV: return fa::splitkv_supported(dtype, D);
     case FA_VARIANT_MFMA_SPLIT2: return fa::mfma_split2_supported(dtype, D);
     case FA_VARIANT_MFMA_EXACT: return fa::mfma_supported(dtype, D);
+    case FA_VARIANT_MFMA_H64S2: return fa::mfma_h64s2_supported(dtype, D);
     default: return 0;
   }
 }
@@ -92,6 +94,11 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   // split the keys of every 32-row block over the waves of a workgroup instead (config 2: 15.9 -> 10.6 us)
   const long long blocks128 = (long long)B * H * ((N + 127) / 128);
   if (fa::splitkv_supported(dtype, D) && N > 64 && blocks128 <= 64) return FA_VARIANT_MFMA_SPLITKV;
+  // head_dim 64, 16-bit inputs, at most two 64-row workgroups per CU: 64-row blocks whose wave pairs take the even / odd
+  // tiles -- twice the workgroups and half the sequential tiles (h=8, N=2048 causal: 20.0 (eight-wave form) -> 17.9 us;
+  // 64 heads x 256: 6.6 -> 5.9 us; profiles/r03/ab_h64s2.log)
+  const long long blocks64 = (long long)B * H * ((N + 63) / 64);
+  if (fa::mfma_h64s2_supported(dtype, D) && N >= 256 && blocks64 <= 512) return FA_VARIANT_MFMA_H64S2;
   // up to one 128-row workgroup per CU: the block's tiles are the critical path -- eight waves, even / odd tiles
   // (h=32, N=1024 causal: 16.1 -> 14.2 us; h=8, N=2048: 27.3 -> 22.0 us, split-KV 25.1)
   if (fa::mfma_split2_supported(dtype, D) && N >= 512 && blocks128 <= 256) return FA_VARIANT_MFMA_SPLIT2;
@@ -107,6 +114,7 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
     case FA_VARIANT_MFMA_PP: snprintf(name, sizeof(name), "fa::fwd_pp_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_SPLITKV: snprintf(name, sizeof(name), "fa::fwd_splitkv_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_SPLIT2: snprintf(name, sizeof(name), "fa::fwd_mfma_split2_kernel<%s, %d, %s>", tag, D, c); break;
+    case FA_VARIANT_MFMA_H64S2: snprintf(name, sizeof(name), "fa::fwd_mfma_h64s2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA:
       snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s, %s>", tag, D, c,
                (dtype != FA_DTYPE_FP8_E4M3 && D <= 128) ? "true" : "false");  // pre-scaled operand where it exists
@@ -178,6 +186,7 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
     case FA_VARIANT_MFMA_PP: e = fa::launch_pp(p, dtype, s); break;
     case FA_VARIANT_MFMA_SPLITKV: e = fa::launch_splitkv(p, dtype, s); break;
     case FA_VARIANT_MFMA_SPLIT2: e = fa::launch_mfma_split2(p, dtype, s); break;
+    case FA_VARIANT_MFMA_H64S2: e = fa::launch_mfma_h64s2(p, dtype, s); break;
     default: e = fa::launch_mfma(p, dtype, s); break;
   }
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)

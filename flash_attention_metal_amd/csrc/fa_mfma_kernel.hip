@@ -70,8 +70,13 @@ constexpr bool prescale_applies() {
 // take the even and the odd KV tiles of the same 128 query rows -- each half with its own K/V buffers, staging and
 // (m, l, O^T) -- and merge once through LDS by their reference maxima. Halves the sequential tile count of a block.
 // PRESC: the pre-scaled query operand (see PRE below); false = every score scaled in fp32 (variant mfma_exact).
-template <typename Tag, int D, bool CAUSAL, int SPLIT, bool PRESC>
+// ROWS: query rows per workgroup, 128 (four row groups of 32 = four waves per split) or 64 (two): "h64s2" = 64 rows x 2 splits
+// is a four-wave workgroup whose wave pairs take the even / odd KV tiles -- twice the workgroups and half the sequential
+// tiles of a block, for causal grids whose critical path is the heaviest q block (N <= 2048 at 64 heads).
+template <typename Tag, int D, bool CAUSAL, int SPLIT, bool PRESC, int ROWS = BM>
 __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
+  constexpr int RW = ROWS / WM;   // row groups = waves per split
+  constexpr int ST = 64 * RW;     // threads per split (the staging map's width)
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -86,7 +91,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   constexpr int GB = IS_FP8 ? 1 : 2;        // bytes per element in HBM
   constexpr int GRB = D * GB;               // global row bytes
   constexpr int GTILE = BN * GRB;           // global bytes of one K (or V) tile
-  constexpr int NCH = BN * (GRB / 16) / NTHREADS;  // staged 16-byte global chunks per thread per tile
+  constexpr int NCH = BN * (GRB / 16) / ST;  // staged 16-byte global chunks per thread per tile
   constexpr bool VPRE = (D == 64) && !IS_FP8;  // prefetch V^T fragments under the QK^T MFMAs
   // Pre-scaled operand (f16/bf16): the Q fragments are multiplied by c = scale.log2(e) and rounded back to the input
   // type ONCE per block, and the running reference -m (log2 units) is the C operand of the first MFMA of every score
@@ -105,15 +110,15 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int sp = (SPLIT == 1) ? 0 : (wave_all >> 2);  // which KV split this wave works on
+  const int sp = (SPLIT == 1) ? 0 : (wave_all / RW);  // which KV split this wave works on
   constexpr int GROUP_LDS = 2 * KTILE + 2 * TILE;     // K and V double buffers of one split
   lds_char *smem = (lds_char *)smem_generic + sp * GROUP_LDS;
   lds_char *Kbuf = smem;              // [2][BN][KRB], rows swizzled
   lds_char *Vbuf = smem + 2 * KTILE;  // [2][BN][RB], rows swizzled
 
-  const int tid = threadIdx.x & (NTHREADS - 1);  // thread within its split's 4 waves (staging map)
+  const int tid = threadIdx.x & (ST - 1);  // thread within its split's waves (staging map)
   const int lane = tid & 63;
-  const int wave = wave_all & 3;                 // row group: query rows 32*wave .. +31 of the block
+  const int wave = wave_all & (RW - 1);          // row group: query rows 32*wave .. +31 of the block
   const int r = lane & 31;  // query within the wave / key row within a block
   const int h = lane >> 5;  // lane half
 
@@ -126,7 +131,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   // grouped-query heads: query head h reads key/value head h / (H / Hkv); Nk keys per head.
   // Causal with Nq != Nk is bottom-right aligned: key j visible to query i iff j <= i + coff.
   const int coff = p.Nk - p.N;
-  const int q0 = qb * BM;
+  const int q0 = qb * ROWS;
   const int qw0 = q0 + wave * WM;  // first query row of this wave
   const int qrow = qw0 + r;
 
@@ -195,7 +200,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   int st_g[NCH], st_k[NCH], st_v[NCH], st_k1[IS_FP8 ? NCH : 1], st_v1[IS_FP8 ? NCH : 1];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int c = tid + i * NTHREADS;
+    const int c = tid + i * ST;
     const int row = c / GCPR, gch = c % GCPR;
     st_g[i] = row * GRB + gch * 16;
     const int skx = (D == 32) ? ((row >> 2) & 3) : (D == 64) ? ((row >> 1) & 7) : (row & 15);
@@ -212,7 +217,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
     }
   }
 
-  const int kv_end = CAUSAL ? min(p.Nk, q0 + BM + coff) : p.Nk;
+  const int kv_end = CAUSAL ? min(p.Nk, q0 + ROWS + coff) : p.Nk;
   const int nT = (kv_end + BN - 1) / BN;
 
   u32x4 kst[NCH], vst[NCH];
@@ -577,7 +582,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
     // reference maxima (a split that saw no tile has m = -inf, l = 0: weight 0). The buffer sits behind the epilogue's
     // O tiles; the K/V buffers are free (last step's barrier).
     constexpr int NACC = 16 * DB;
-    float *mb = (float *)((lds_char *)smem_generic + (BM / WM) * WM * RB) + (size_t)wave * (NACC + 2) * 64 + lane;
+    float *mb = (float *)((lds_char *)smem_generic + RW * WM * RB) + (size_t)wave * (NACC + 2) * 64 + lane;
     if (sp == 1) {
 #pragma unroll
       for (int db = 0; db < DB; ++db)
@@ -653,6 +658,11 @@ __global__ __launch_bounds__(2 * NTHREADS, 2) void fwd_mfma_split2_kernel(Params
   fwd_mfma_body<Tag, D, CAUSAL, 2, true>(p);
 }
 
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, 2) void fwd_mfma_h64s2_kernel(Params p) {
+  fwd_mfma_body<Tag, D, CAUSAL, 2, true, 64>(p);
+}
+
 // ---------------------------------------------------------------------------
 bool mfma_supported(int dtype, int D) {
   if (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) return D == 32 || D == 64 || D == 96 || D == 128 || D == 256;
@@ -709,6 +719,35 @@ static hipError_t launch_split2_one(const Params &p, hipStream_t s) {
   (void)hipGetLastError();
   hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(2 * NTHREADS), smem, s, pp);
   return hipGetLastError();
+}
+
+template <typename Tag, int D, bool CAUSAL>
+static hipError_t launch_h64s2_one(const Params &p, hipStream_t s) {
+  constexpr int ROWS = 64;
+  const int nQ = (p.N + ROWS - 1) / ROWS;
+  const size_t vrow = D * 2;
+  const size_t group = 2 * BN * (std::is_same<Tag, FP8>::value ? (size_t)D : vrow) + 2 * BN * vrow;  // as launch_one
+  const size_t merge_end = (size_t)ROWS * vrow + (size_t)(ROWS / WM) * (16 * (D / 32) + 2) * 64 * 4;
+  const size_t smem = std::max(2 * group, merge_end);
+  auto kern = fwd_mfma_h64s2_kernel<Tag, D, CAUSAL>;
+  if (smem > 48 * 1024) {
+    hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  Params pp = p;
+  pp.head_group = 0;
+  set_block_divisors(pp, nQ, 0);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
+  return hipGetLastError();
+}
+
+bool mfma_h64s2_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D == 64; }
+
+hipError_t launch_mfma_h64s2(const Params &p, int dtype, hipStream_t s) {
+  if (p.D != 64) return hipErrorInvalidValue;
+  if (dtype == FA_DTYPE_F16) return p.is_causal ? launch_h64s2_one<F16, 64, true>(p, s) : launch_h64s2_one<F16, 64, false>(p, s);
+  return p.is_causal ? launch_h64s2_one<BF16, 64, true>(p, s) : launch_h64s2_one<BF16, 64, false>(p, s);
 }
 
 bool mfma_split2_supported(int dtype, int D) {

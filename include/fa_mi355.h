@@ -61,9 +61,12 @@ enum fa_variant {
   FA_VARIANT_MFMA_SPLIT2 = 7, /* same operator for grids that fill part of the chip: the 128-row workgroup of MFMA with eight
                             waves, waves 0-3 / 4-7 taking the even / odd KV tiles and merging once (halves the sequential
                             tile count of a block; head_dim 64, 128) */
-  FA_VARIANT_MFMA_EXACT = 8 /* FA_VARIANT_MFMA without the pre-scaled query operand: every score is scaled in fp32 (one more
+  FA_VARIANT_MFMA_EXACT = 8, /* FA_VARIANT_MFMA without the pre-scaled query operand: every score is scaled in fp32 (one more
                             FMA per score, 6-8 % slower at head_dim 64). For logits far larger than a trained model
                             produces; see "LSE accuracy" below. Identical to FA_VARIANT_MFMA for fp8 inputs and D = 256 */
+  FA_VARIANT_MFMA_H64S2 = 9 /* same operator, 64 query rows per workgroup: four waves, the two wave pairs take the even / odd
+                            KV tiles and merge once (twice the workgroups, half the sequential tiles of a block): grids
+                            whose critical path is the heaviest causal block (f16 / bf16, head_dim 64) */
 };
 
 /* status codes (0 = success, negative = error; text via fa_last_error()) */

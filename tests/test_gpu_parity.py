@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 TOL_O = {"f32": 2e-5, "f16": 1.5e-3, "bf16": 6e-3}
 TOL_LSE = {"f32": 2e-5, "f16": 1e-4, "bf16": 1e-4}
 # the matrix-core kernels: 128-row workgroups ("mfma"), paired-block pipeline ("mfma_pp"); "auto" picks by grid size
-MFMA_VARIANTS = ["mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact"]
+MFMA_VARIANTS = ["mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2"]
 
 
 def need(fa, dtype, variant, D):
@@ -135,6 +135,7 @@ def test_fp8_equals_bf16_kernel_on_same_values(fa, oracle_mod, variant):
     # e4m3 -> bf16 is exact, so the fp8-input kernel must reproduce the bf16 kernel bit for bit
     import torch
 
+    need(fa, "fp8", variant, 64)
     q, k, v = make_qkv(oracle_mod, 2, 4, 320, 64, "fp8", amp=2.0)
     for causal in (False, True):
         o8, l8 = run_op(fa, q, k, v, "fp8", causal, variant)
@@ -170,7 +171,7 @@ def test_causal_row0_is_v0_bit_exact(fa, oracle_mod, dtype, variant):
 
 @pytest.mark.parametrize("variant,dtype", [("mfma", "bf16"), ("mfma", "f16"), ("mfma_pp", "bf16"), ("mfma_pp", "f16"),
                                            ("mfma_splitkv", "bf16"), ("mfma_splitkv", "f16"), ("mfma_split2", "bf16"), ("mfma_split2", "f16"),
-                                           ("mfma_exact", "bf16"), ("mfma", "fp8"), ("mfma_pp", "fp8"), ("mfma_splitkv", "fp8"), ("mfma_split2", "fp8"),
+                                           ("mfma_exact", "bf16"), ("mfma_h64s2", "bf16"), ("mfma_h64s2", "f16"), ("mfma", "fp8"), ("mfma_pp", "fp8"), ("mfma_splitkv", "fp8"), ("mfma_split2", "fp8"),
                                            ("tiled_v2", "f32"), ("tiled", "f32"), ("naive", "f32")])
 def test_mask_index_probe_exact(fa, oracle_mod, variant, dtype):
     # Q = 0 -> uniform softmax; V[j,0] = delta(j,t): causal O[i,0] = 1/(i+1) for i >= t, EXACTLY 0 left of it.
@@ -537,10 +538,12 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
     V = fa.VARIANTS
     cases = [  # (B, H, N, D, dtype, causal, expected variant)
         (1, 8, 1024, 64, "f16", False, "mfma_splitkv"),    # BASELINE config 2: 64 blocks of 128 rows <= 64
-        (1, 8, 1040, 64, "bf16", True, "mfma_split2"),     # 72 blocks: just past the split-KV rule, N >= 512
-        (1, 64, 512, 64, "bf16", True, "mfma_split2"),     # 256 blocks: the last grid of the eight-wave form
-        (1, 65, 512, 64, "bf16", False, "mfma"),           # 260 blocks: first grid of the plain 128-row kernel
-        (1, 80, 256, 64, "bf16", True, "mfma"),            # N < 512: never the eight-wave form
+        (1, 8, 1040, 64, "bf16", True, "mfma_h64s2"),      # 72 blocks of 128 rows: just past the split-KV rule; 136 blocks of 64 rows
+        (1, 64, 512, 64, "bf16", True, "mfma_h64s2"),      # 512 blocks of 64 rows: the last grid of the 64-row two-split form
+        (1, 65, 512, 64, "bf16", False, "mfma"),           # 520 blocks of 64 rows, 260 of 128: first grid of the plain 128-row kernel
+        (1, 80, 256, 64, "bf16", True, "mfma_h64s2"),      # 320 blocks of 64 rows, N >= 256
+        (1, 200, 128, 64, "f16", True, "mfma"),            # N < 256: plain kernel
+        (1, 40, 512, 64, "fp8", True, "mfma_split2"),      # fp8 keeps the eight-wave form (160 blocks of 128 rows)
         (2, 3, 64, 64, "f16", True, "mfma"),               # N <= 64: a single tile, never split-KV
         (1, 2, 4096, 128, "bf16", True, "mfma_splitkv"),   # head_dim 128, 64 blocks
         (1, 16, 2048, 128, "bf16", True, "mfma_split2"),   # 256 blocks of 128 rows, N < 4096
