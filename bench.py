@@ -128,10 +128,13 @@ def spawn_ranks(args) -> int:
     return max(abs(rc) for rc in rcs)
 
 
-def timed_launches(torch, stream, step, steps, block=10):
-    """K launches, HIP events on the launch stream around blocks of `block` (an event pair around every
-    single launch puts a bubble between kernels). Returns (wall seconds incl. final sync handled by caller's
-    barrier, per-launch ms sorted, total ms)."""
+def timed_launches(torch, stream, step, steps, block=None):
+    """K launches, HIP events on the launch stream around blocks of launches (an event pair around every single launch puts
+    a bubble between kernels, and so does every pair inside the timed region: a timing event is a barrier packet plus a
+    signal -- with pairs every 10 launches the 20-step run's wall time read 6 % over its own kernel time). Blocks of
+    max(20, K/4) launches: one pair for the driver's K = 20, four for the default K = 200."""
+    if block is None:
+        block = max(20, steps // 4)
     blocks = [(i, min(i + block, steps)) for i in range(0, steps, block)]
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in blocks]
     for (lo_i, hi_i), (a, b) in zip(blocks, evs):
@@ -197,8 +200,10 @@ def main() -> int:
     lse = torch.empty(1, my, N, dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
-    def step():
-        fa.flash_attention_forward(q, k, v, is_causal=CAUSAL, out=o, lse=lse)
+    # validated once, launched K times (the reference host encodes its argument table per dispatch too, main.mm:821-852):
+    # the Python-side checks of flash_attention_forward cost ~15 us per call, which matters for a 3 ms timed region
+    plan = fa.ForwardPlan(q, k, v, is_causal=CAUSAL, out=o, lse=lse)
+    step = plan.launch
 
     def barrier():
         ranks.barrier(info, dev)
@@ -288,8 +293,7 @@ def c4_slice(fa, torch, ranks, info, dev, iters=10):
     o = torch.empty_like(q)
     lse = torch.empty(1, C4_SLICES, C4_N, dtype=torch.float32, device=dev)
 
-    def step():
-        fa.flash_attention_forward(q, k, v, is_causal=True, out=o, lse=lse)
+    step = fa.ForwardPlan(q, k, v, is_causal=True, out=o, lse=lse).launch
 
     for _ in range(3):
         step()

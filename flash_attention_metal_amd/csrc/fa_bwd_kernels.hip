@@ -454,19 +454,20 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
       vec8 pf[2][2], df[2][2];
       // only tiles that cross the diagonal for this wave need the per-element mask (wave-uniform)
       const bool need_mask = CAUSAL && (qt0 < kw0 + WM - 1);
+      if (need_mask) {  // key > query (kernels.metal:748): S' = -inf there. A wave-uniform BRANCH: written as a per-element
+#pragma unroll          // condition hipcc turned it into 32 compare + select pairs on every tile (seen in the ISA)
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            s[qb][i] = (qt0 + 32 * qb + 8 * (i >> 2) + 4 * h + (i & 3) < krow) ? -INFINITY : s[qb][i];
+      }
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int ql = 32 * qb + 8 * g + 4 * h;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int i = 4 * g + e;
-            float pv = __builtin_amdgcn_exp2f(s[qb][i]);  // S' = Q.K~ - lse*log2e came out of the matrix core
-            if (need_mask && (qt0 + ql + e < krow)) pv = 0.0f;  // key > query (kernels.metal:748)
-            s[qb][i] = pv;
-            dp[qb][i] = pv * dp[qb][i];  // dS (without the softmax scale: it goes onto the finished dK)
-          }
+        for (int i = 0; i < 16; ++i) {
+          const float pv = __builtin_amdgcn_exp2f(s[qb][i]);  // S' = Q.K~ - lse*log2e came out of the matrix core
+          s[qb][i] = pv;
+          dp[qb][i] = pv * dp[qb][i];  // dS (without the softmax scale: it goes onto the finished dK)
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
