@@ -117,7 +117,7 @@ def test_bench_parent_process_never_imports_torch_or_the_library():
     src = open(os.path.join(ROOT, "bench.py")).read()
     top_imports = [l for l in src.splitlines() if l.startswith(("import ", "from "))]
     assert top_imports and not any("torch" in l or "flash_attention_metal_amd" in l for l in top_imports)
-    body = src[src.index("def spawn_ranks"):src.index("def timed_launches")]
+    body = src[src.index("def spawn_ranks"):src.index("def make_events")]
     code = "\n".join(l for l in body.splitlines() if not l.strip().startswith(("#", '"""')) and "imports neither" not in l)
     assert "import torch" not in code and "torch." not in code and "os.exec" not in code and "subprocess.Popen" in code
     main = src[src.index("def main()"):]
