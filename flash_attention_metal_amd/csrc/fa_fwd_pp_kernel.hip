@@ -32,6 +32,11 @@
 #ifndef FA_PP_THR
 #define FA_PP_THR 8.0f  // log2 units: P values are bounded by 2^8 between rescales
 #endif
+#ifndef FA_PP_DMA
+#define FA_PP_DMA 1  // 1 (16-bit inputs): K/V tiles of the loop go global -> LDS by LDS-DMA (buffer_load ... lds), no staging registers, no ds_write:
+                     // +4.5..5.3 % at head_dim 128 (config 4 1131 -> 1192), bit-identical outputs (profiles/r03/ab_pp_lds_dma.log); 0 = round 2's
+                     // global -> asm-owned AGPR -> ds_write path
+#endif
 #ifndef FA_PP_LA
 #define FA_PP_LA 2      // LDS fragment reads are issued this many fragments (= 2 MFMAs each) ahead of their use
 #endif
@@ -53,7 +58,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
   constexpr int NACC_O = 2 * DB * 16;            // O^T of block x, d block db = a[16(x DB + db) ..+15]
   constexpr int NACC_Q = NACC_O + 2 * KS * 4;    // + Q fragment (x, ks) = a[NACC_O + 4(x KS + ks) ..+3]
   constexpr bool ASM_STAGE = !std::is_same<Tag, FP8>::value;  // 16-bit inputs: the loop's K/V staging registers are asm-owned too
-  constexpr int NST = ASM_STAGE ? 2 * (BN * (D * 2 / 16) / NTHREADS) * 4 : 0;  // a[NACC_Q + 4 i ..+3] = staged chunk i (K chunks, then V chunks)
+  constexpr bool DMA = (FA_PP_DMA != 0) && ASM_STAGE;  // LDS-DMA staging in the loop (A/B: profiles/r03/ab_pp_lds_dma.log)
+  constexpr int NST = (ASM_STAGE && !DMA) ? 2 * (BN * (D * 2 / 16) / NTHREADS) * 4 : 0;  // a[NACC_Q + 4 i ..+3] = staged chunk i (K chunks, then V chunks)
   constexpr int NACC = NACC_Q + NST;
   constexpr int TILE = BN * RB;             // bytes of one K (or V) tile in LDS
   constexpr bool IS_FP8 = std::is_same<Tag, FP8>::value;
@@ -134,6 +140,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     }
   }
 
+  // LDS-DMA source offsets (FA_PP_DMA): lane L of wave w writes LDS bytes [16 L, 16 L + 16) of piece w (+4j): row
+  // RPP w + L / GCPR, physical chunk L % GCPR, which holds logical chunk (L % GCPR) ^ swizzle(row)
+  unsigned dma_kvo = 0, dma_vvo = 0;
+  {
+    constexpr int RPP = 1024 / RB;  // rows per 1-KiB piece
+    const int row = wave * RPP + lane / GCPR, pc = lane % GCPR;
+    const int skx = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    const int svx = (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+    dma_kvo = (unsigned)(row * GRB + ((pc ^ skx) << 4));
+    dma_vvo = (unsigned)(row * GRB + ((pc ^ svx) << 4));
+    static_assert(IS_FP8 || (4 * RPP * RB == 4096 && (D == 64 ? (4 * 4 * RPP) % 16 == 0 : (4 * RPP) % 16 == 0)), "piece stride keeps the swizzle");
+  }
+  (void)dma_kvo; (void)dma_vvo;
   // tiles: the workgroup stages nT tiles; this wave computes the first nTw of them. Iteration t is "hot"
   // when tile t+1 exists for this wave and needs no mask for either block (tile t was masked, if at all,
   // by the iteration before).
@@ -331,7 +350,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
 
   // ================= phase Q: S(A,B) = K.Q^T of the next tile  ||  finish softmax of the current one: pe -> P, l =================
   // K tile in Kbuf[kbuf]; HAS_QK = false on the wave's last tile (nothing left to score).
-  auto phase_q = [&](auto hasqkc, const int kbuf) __attribute__((always_inline)) {
+  auto phase_q = [&](auto hasqkc, const int kbuf, auto &&dma) __attribute__((always_inline)) {
     constexpr bool HAS_QK = decltype(hasqkc)::value;
     constexpr int NF = HAS_QK ? 2 * KS : 0;  // fragments (kb, ks); each feeds 2 MFMAs (block A, block B)
     constexpr int NG = HAS_QK ? 2 * NF : 1;  // gap groups
@@ -357,6 +376,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
         constexpr int f = g / 2, x = g % 2, kb = f / KS, ks = f % KS;
         mfma_v_qacc<Tag, NACC, NACC_O + 4 * (x * KS + ks), ks == 0>(s[x][kb], kf[f]);
         if constexpr (x == 1 && f + LA < NF) kread(std::integral_constant<int, f + LA>{});
+      }
+      if constexpr (DMA) {  // the next tiles' LDS-DMA pieces, spread over the first half of the phase (they must land before the barrier)
+        constexpr int GD = NG > 1 ? NG / 2 : 1;
+        if constexpr (g < GD) static_for<g * NPIECE / GD, (g + 1) * NPIECE / GD>([&](auto ic) __attribute__((always_inline)) { dma(ic); });
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -498,7 +521,22 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     // the LDS image with the same swizzle (the swizzle period divides ROWS_PER_CHUNK): one per-lane address each,
     // the rest is a scalar / immediate offset.
     constexpr int ROWS_PER_CHUNK = NTHREADS / GCPR;
-    if constexpr (ASM_STAGE) {
+    // LDS-DMA form: wave w moves the 1-KiB pieces w, w+4, ... of each tile; the LDS image is lane-linear inside a piece, so
+    // the chunk swizzle sits on the SOURCE address (dma_kvo / dma_vvo, one per-lane offset each); M0 = the piece's LDS address
+    auto dma = [&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (DMA) {
+        constexpr bool ISK = i < NCH;
+        constexpr int j = i % NCH;
+        const unsigned lds = (unsigned)(__UINTPTR_TYPE__)(ISK ? Kbuf : Vbuf) + (ISK ? PAR : (PAR ^ 1)) * TILE + (wave + 4 * j) * 1024;
+        const unsigned soff = (unsigned)(t + (ISK ? 2 : 1)) * GTILE + j * 4096;
+        const unsigned vo = ISK ? dma_kvo : dma_vvo;
+        const __amdgpu_buffer_rsrc_t rs = ISK ? rk : rv;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds), "v"(vo), "s"(rs), "s"(soff) : "memory");
+      }
+    };
+    if constexpr (DMA) {
+    } else if constexpr (ASM_STAGE) {
       const unsigned gk = (unsigned)(t + 2) * GTILE + st_g[0], gv = (unsigned)(t + 1) * GTILE + st_g[0];
       static_for<0, NCH>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
@@ -514,7 +552,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
     }
     auto stage = [&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (ASM_STAGE) {
+      if constexpr (DMA) {
+      } else if constexpr (ASM_STAGE) {
         lds_char *dst = (i < NCH) ? Kbuf + st_k[0] : Vbuf + st_v[0];
         constexpr int OFF = ((i < NCH) ? PAR : (PAR ^ 1)) * TILE + (i % NCH) * ROWS_PER_CHUNK * RB;
         acc_lds_write_b128<NACC, NACC_Q + 4 * i, NPIECE - 1 - i, OFF>((unsigned)(__UINTPTR_TYPE__)dst);
@@ -524,20 +563,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void fwd_pp_kernel(Params p) {
       }
     };
     if (t < nHot) {                               // hot: tile t+1 exists and needs no mask
-      phase_q(T{}, PK{});
+      phase_q(T{}, PK{}, dma);
       phase_p(T{}, F{}, PV{}, t + 1, stage);
     } else if (t < nTw) {
       if (t + 1 < nTw) {                          // cold: tile t+1 is masked
-        phase_q(T{}, PK{});
+        phase_q(T{}, PK{}, dma);
         phase_p(T{}, T{}, PV{}, t + 1, stage);
       } else {                                    // this wave's last tile: drain
-        phase_q(F{}, PK{});
+        phase_q(F{}, PK{}, dma);
         phase_p(F{}, F{}, PV{}, t + 1, stage);
       }
     } else {                                      // this wave is done (causal): it only keeps staging for the others
-      static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { stage(ic); });
+      static_for<0, NPIECE>([&](auto ic) __attribute__((always_inline)) { stage(ic); dma(ic); });
     }
-    if constexpr (ASM_STAGE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not count the asm LDS stores
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA pieces of this iteration have landed (hipcc does not count them)
+    else if constexpr (ASM_STAGE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // hipcc does not count the asm LDS stores
     __syncthreads();
   };
   for (int t = 0; t < nT; t += 2) {
