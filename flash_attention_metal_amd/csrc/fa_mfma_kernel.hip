@@ -44,11 +44,15 @@
 #ifndef FA_VPRE_HALF
 #define FA_VPRE_HALF 1  // 1: only the first 32 keys' V^T fragments are prefetched under the QK^T MFMAs, the second half under the first half's PV MFMAs (-16 live registers)
 #endif
-#ifndef FA_LAK
-#define FA_LAK 2  // head dims other than 64: K fragments are read this many MFMAs ahead of their use
+#ifndef FA_MFMA_DMA
+#define FA_MFMA_DMA 1  // 1 (f16/bf16, head_dim 32/64/128): K/V tiles go global -> LDS by LDS-DMA (buffer_load ... lds), no staging registers, no
+                       // ds_write: config 3 +6.7 %, head_dim 128 +9..11 %, bit-identical outputs (profiles/r03/ab_mfma_lds_dma.log); 0 = register staging
 #endif
+#ifndef FA_LAK
+#define FA_LAK (D == 128 ? 4 : 2)  // head dims other than 64: K fragments are read this many MFMAs ahead of their use (head_dim 128: 4 since the
+#endif                             // LDS-DMA staging freed the registers: +1..2 %, profiles/r03/ab_dma_knobs.log)
 #ifndef FA_LAV
-#define FA_LAV 2  // ... and V^T fragments
+#define FA_LAV (D == 128 ? 4 : 2)  // ... and V^T fragments
 #endif
 #ifndef FA_PRIO
 #define FA_PRIO 2  // wave priority: 2 = raised around the MFMA clusters (+0.4..0.9 % A/B), 1 = around the softmax (-1..-6 %), 0 = off
@@ -220,6 +224,30 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   const int kv_end = CAUSAL ? min(p.Nk, q0 + ROWS + coff) : p.Nk;
   const int nT = (kv_end + BN - 1) / BN;
 
+  // LDS-DMA staging (FA_MFMA_DMA): wave w of a split moves the 1-KiB pieces w, w + RW, ... of each tile; inside a piece the
+  // LDS image is lane-linear, so the chunk swizzle sits on the SOURCE address (one per-lane offset for K, one for V)
+  constexpr bool DMA = (FA_MFMA_DMA != 0) && !IS_FP8 && (D == 32 || D == 64 || D == 128);
+  constexpr int RPP = 1024 / RB;                 // rows per piece
+  constexpr int NPW = (BN / RPP) / RW;           // pieces per wave, tile and operand
+  unsigned dma_kvo = 0, dma_vvo = 0;
+  if constexpr (DMA) {
+    static_assert((RW * RPP) % 16 == 0 || D == 32, "the piece stride must keep the swizzle");
+    const int row = wave * RPP + lane / CPRL, pc = lane % CPRL;
+    const int skx = (D == 32) ? ((row >> 2) & 3) : (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    const int svx = (D == 32) ? 0 : (D == 64) ? (((row >> 1) & 1) << 2) : ((row & 3) << 2);
+    dma_kvo = (unsigned)(row * GRB + ((pc ^ skx) << 4));
+    dma_vvo = (unsigned)(row * GRB + ((pc ^ svx) << 4));
+  }
+  auto stage_dma = [&](int t, int buf) {  // tile t -> buffer buf (hipcc does not count these loads: the caller waits vmcnt(0))
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const unsigned soff = (unsigned)t * GTILE + j * (RW * 1024);
+      const unsigned lk = (unsigned)(__UINTPTR_TYPE__)Kbuf + buf * KTILE + (wave + RW * j) * 1024;
+      const unsigned lv = (unsigned)(__UINTPTR_TYPE__)Vbuf + buf * TILE + (wave + RW * j) * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dma_kvo), "s"(rk), "s"(soff) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lv), "v"(dma_vvo), "s"(rv), "s"(soff) : "memory");
+    }
+  };
   u32x4 kst[NCH], vst[NCH];
   auto stage_load = [&](int t) {
     const unsigned g0 = (unsigned)t * GTILE;  // tile t starts at key t*BN
@@ -261,8 +289,13 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   for (int i = 0; i < 16; ++i) negm[i] = 0.0f;
   if constexpr (PRE) asm volatile("" : "+v"(negm));  // opaque: else hipcc re-materialises the splat in front of every MFMA
 
-  stage_load(sp);  // this split's first tile (past the end of a short head: zeros through the descriptor, never used)
-  stage_write(0);
+  if constexpr (DMA) {
+    stage_dma(sp, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    stage_load(sp);  // this split's first tile (past the end of a short head: zeros through the descriptor, never used)
+    stage_write(0);
+  }
   // Retire the Q-fragment loads HERE: hipcc's waitcnt pass otherwise carries them into the
   // loop as "possibly pending" and drains vmcnt(0) in front of every tile's first MFMAs, i.e.
   // waits for the prefetch it has just issued (seen in the .s as vmcnt(3)..vmcnt(0)).
@@ -324,7 +357,10 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   auto tile = [&](auto bufc, const int t) {
     constexpr int buf = decltype(bufc)::value;
     const int kv0 = t * BN;
-    if (t + SPLIT < nT) stage_load(t + SPLIT);  // this split's next tile, in flight under this tile's MFMAs
+    if (t + SPLIT < nT) {  // this split's next tile, in flight under this tile's MFMAs
+      if constexpr (DMA) stage_dma(t + SPLIT, buf ^ 1);
+      else stage_load(t + SPLIT);
+    }
 
     // whole-tile skip per wave (kernels.metal:682 with Br = 32): every key of
     // the tile is past this wave's last query row
@@ -568,7 +604,10 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
         }
       }
     }
-    if (t + SPLIT < nT) stage_write(buf ^ 1);
+    if (t + SPLIT < nT) {
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this tile have landed
+      else stage_write(buf ^ 1);
+    }
     __syncthreads();
   };
   const int steps = (nT + SPLIT - 1) / SPLIT;  // every wave runs the same number of steps (one barrier each)
