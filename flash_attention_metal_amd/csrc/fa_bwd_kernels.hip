@@ -48,6 +48,9 @@ struct BwdParams {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+#ifndef FA_BWD_DMA
+#define FA_BWD_DMA 1  // 1: the streamed tiles go global -> LDS by LDS-DMA (buffer_load ... lds; the chunk swizzle sits on the source address):
+#endif                // no staging registers, no ds_write_b128 (as in the forward kernels, profiles/r03/ab_mfma_lds_dma.log); 0 = register staging
 #ifndef FA_BWD_SUB
 #define FA_BWD_SUB 2  // 64-row sub-tiles per staged tile: one barrier and one staging pass per FA_BWD_SUB * 64 keys (dQ) / queries (dK, dV)
 #endif
@@ -73,7 +76,15 @@ constexpr int BT = BSUB * BN;  // rows of a staged tile
     const int row = 8 * variant + 4 * h_ + vq_; /* a representative R0 = 8 * variant */        \
     return (4 * h_ + vq_) * BRB + ((((4 * db) + 2 * g1_ + (vp_ >> 1)) ^ u_swz(row)) << 4) + 8 * (vp_ & 1); \
   };                                                                                          \
-  (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)STILE; (void)u_swz; (void)tr_off; (void)NTV
+  /* LDS-DMA: wave w moves the 1-KiB pieces w, w+4, ... of a staged tile; lane L fills LDS bytes [16 L, 16 L + 16) of its    */ \
+  /* piece = row RPP w + L / BCPR, physical chunk L % BCPR, which holds logical chunk (L % BCPR) ^ u_swz(row); the swizzle */ \
+  /* does not depend on the piece index (4 RPP rows per step of the piece index: a multiple of its period)                */ \
+  constexpr int RPP = 1024 / BRB, NPW = (BT / RPP) / 4;                                       \
+  auto dma_off = [&](int wave_, int lane_) {                                                  \
+    const int row = wave_ * RPP + lane_ / BCPR, pc = lane_ % BCPR;                            \
+    return (unsigned)(row * BRB + ((pc ^ u_swz(row)) << 4));                                  \
+  };                                                                                          \
+  (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)STILE; (void)u_swz; (void)tr_off; (void)NTV; (void)RPP; (void)NPW; (void)dma_off
 
 // ---------------------------------------------------------------------------
 // dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
@@ -156,19 +167,40 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   const int kv_end = CAUSAL ? min(p.N, q0 + BM) : p.N;
   const int nT = (kv_end + BT - 1) / BT;
 
-  u32x4 kst[NCH], vst[NCH];
-  auto stage_load = [&](int t) {
+  constexpr bool DMA = FA_BWD_DMA != 0;
+  const unsigned dvo = dma_off(wave, lane);
+  // tile t -> buffer buf by LDS-DMA (hipcc does not count these loads: stage_write waits vmcnt(0))
+  auto stage_dma = [&](int t, int buf) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)t * STILE + st_g[i], 0, 0);
-      vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)t * STILE + st_g[i], 0, 0);
+    for (int j = 0; j < NPW; ++j) {
+      const unsigned soff = (unsigned)t * STILE + j * 4096;
+      const unsigned lk = (unsigned)(__UINTPTR_TYPE__)KU + buf * STILE + (wave + 4 * j) * 1024;
+      const unsigned lv = (unsigned)(__UINTPTR_TYPE__)VR + buf * STILE + (wave + 4 * j) * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dvo), "s"(rk), "s"(soff) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lv), "v"(dvo), "s"(rv), "s"(soff) : "memory");
+    }
+  };
+  u32x4 kst[NCH], vst[NCH];
+  auto stage_load = [&](int t, int buf) {
+    if constexpr (DMA) {
+      stage_dma(t, buf);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)t * STILE + st_g[i], 0, 0);
+        vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)t * STILE + st_g[i], 0, 0);
+      }
     }
   };
   auto stage_write = [&](int buf) {
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      lds_write_b128(KU + buf * STILE + st_r[i], kst[i]);
-      lds_write_b128(VR + buf * STILE + st_r[i], vst[i]);
+      for (int i = 0; i < NCH; ++i) {
+        lds_write_b128(KU + buf * STILE + st_r[i], kst[i]);
+        lds_write_b128(VR + buf * STILE + st_r[i], vst[i]);
+      }
     }
   };
 
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
 #pragma unroll
     for (int i = 0; i < 16; ++i) dqacc[db][i] = 0.0f;
 
-  stage_load(0);
+  stage_load(0, 0);
   stage_write(0);
 #pragma unroll
   for (int ks = 0; ks < BKS; ++ks)  // Q~ = round(c.Q): the very operand the forward multiplied (fa_mfma_kernel.hip)
@@ -190,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
 
   for (int t = 0; t < nT; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nT) stage_load(t + 1);
+    if (t + 1 < nT) stage_load(t + 1, buf ^ 1);
 #pragma unroll
     for (int sub = 0; sub < BSUB; ++sub) {
     const int kv0 = t * BT + sub * BN;
@@ -347,11 +379,24 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
   // iteration (seen in the ISA: the memory latency was exposed once per tile). It is scaled / negated in stage_write.
   float rowv = 0.0f;
   const float *row_src = (tid < BT ? p.lse : p.delta) + (long long)bh * p.N;
-  auto stage_load = [&](int t) {
+  constexpr bool DMA = FA_BWD_DMA != 0;
+  const unsigned dvo = dma_off(wave, lane);
+  auto stage_load = [&](int t, int buf) {
+    if constexpr (DMA) {  // (hipcc does not count these loads: stage_write waits vmcnt(0))
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      qst[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)t * STILE + st_g[i], 0, 0);
-      ost[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)t * STILE + st_g[i], 0, 0);
+      for (int j = 0; j < NPW; ++j) {
+        const unsigned soff = (unsigned)t * STILE + j * 4096;
+        const unsigned lq = (unsigned)(__UINTPTR_TYPE__)QU + buf * STILE + (wave + 4 * j) * 1024;
+        const unsigned lo = (unsigned)(__UINTPTR_TYPE__)OU + buf * STILE + (wave + 4 * j) * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lq), "v"(dvo), "s"(rq), "s"(soff) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lo), "v"(dvo), "s"(rdo), "s"(soff) : "memory");
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        qst[i] = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)t * STILE + st_g[i], 0, 0);
+        ost[i] = __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)t * STILE + st_g[i], 0, 0);
+      }
     }
     if (tid < 2 * BT) {
       const int qi = t * BT + (tid & (BT - 1));
@@ -359,10 +404,14 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
     }
   };
   auto stage_write = [&](int buf, int wt) {  // wt = the tile the staged registers hold
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      lds_write_b128(QU + buf * STILE + st_r[i], qst[i]);
-      lds_write_b128(OU + buf * STILE + st_r[i], ost[i]);
+      for (int i = 0; i < NCH; ++i) {
+        lds_write_b128(QU + buf * STILE + st_r[i], qst[i]);
+        lds_write_b128(OU + buf * STILE + st_r[i], ost[i]);
+      }
     }
     if (tid < 2 * BT) {  // (the staged registers hold tile wt: its rows past N get p = 0 through -inf)
       const int qi = wt * BT + (tid & (BT - 1));
@@ -378,7 +427,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
     for (int i = 0; i < 16; ++i) { dkacc[db][i] = 0.0f; dvacc[db][i] = 0.0f; }
 
   if (t_begin < nTq) {
-    stage_load(t_begin);
+    stage_load(t_begin, 0);
     stage_write(0, t_begin);
   }
 #pragma unroll
@@ -391,7 +440,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
 
   for (int t = t_begin; t < nTq; ++t) {
     const int buf = (t - t_begin) & 1;
-    if (t + 1 < nTq) stage_load(t + 1);
+    if (t + 1 < nTq) stage_load(t + 1, buf ^ 1);
 #pragma unroll
     for (int sub = 0; sub < BSUB; ++sub) {
     const int qt0 = t * BT + sub * BN;
