@@ -48,6 +48,9 @@
 #define FA_MFMA_DMA 1  // 1 (f16/bf16, head_dim 32/64/128): K/V tiles go global -> LDS by LDS-DMA (buffer_load ... lds), no staging registers, no
                        // ds_write: config 3 +6.7 %, head_dim 128 +9..11 %, bit-identical outputs (profiles/r03/ab_mfma_lds_dma.log); 0 = register staging
 #endif
+#ifndef FA_DMA_LATE
+#define FA_DMA_LATE 0
+#endif
 #ifndef FA_LAK
 #define FA_LAK (D == 128 ? 4 : 2)  // head dims other than 64: K fragments are read this many MFMAs ahead of their use (head_dim 128: 4 since the
 #endif                             // LDS-DMA staging freed the registers: +1..2 %, profiles/r03/ab_dma_knobs.log)
@@ -357,9 +360,13 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   auto tile = [&](auto bufc, const int t) {
     constexpr int buf = decltype(bufc)::value;
     const int kv0 = t * BN;
+    constexpr bool DMA_LATE = DMA && (FA_DMA_LATE != 0);  // issue the LDS-DMA pieces behind the score MFMAs instead of in front of them
     if (t + SPLIT < nT) {  // this split's next tile, in flight under this tile's MFMAs
-      if constexpr (DMA) stage_dma(t + SPLIT, buf ^ 1);
-      else stage_load(t + SPLIT);
+      if constexpr (DMA) {
+        if constexpr (!DMA_LATE) stage_dma(t + SPLIT, buf ^ 1);
+      } else {
+        stage_load(t + SPLIT);
+      }
     }
 
     // whole-tile skip per wave (kernels.metal:682 with Br = 32): every key of
@@ -449,6 +456,9 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
           if (i + LA < NK) kread(i + LA);
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
+      if constexpr (DMA_LATE) {
+        if (t + SPLIT < nT) stage_dma(t + SPLIT, buf ^ 1);
       }
       // ---- mask (only on tiles that cross the diagonal or the end of the sequence)
       const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk);
@@ -604,8 +614,11 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
         }
       }
     }
+    if constexpr (DMA_LATE) {  // a wave that skipped the tile (causal) still moves its pieces
+      if (!wave_active && t + SPLIT < nT) stage_dma(t + SPLIT, buf ^ 1);
+    }
     if (t + SPLIT < nT) {
-      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this tile have landed
+      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued during this tile have landed
       else stage_write(buf ^ 1);
     }
     __syncthreads();
