@@ -79,17 +79,16 @@ int fa_resolve_variant(int dtype, int D) {
   return FA_ERR_UNSUPPORTED;
 }
 
-// AUTO between the matrix-core kernels (interleaved A/B on MI355X): the paired-block kernel
-// (one wave per SIMD, 256-row workgroups) wins at head_dim 128 once the sequence is long (>= 4096) and the grid
-// gives every CU at least two workgroups; the split-KV kernel wins on grids far smaller than the chip, the eight-wave
-// form of the 128-row kernel on grids up to one workgroup per CU; everywhere
-// else -- all of head_dim 64 at scale included -- the 128-row kernel with three waves per SIMD is fastest.
+// AUTO between the matrix-core kernels (interleaved A/B on MI355X): the split-KV kernel wins on
+// grids far smaller than the chip, the 64-row two-split form and the eight-wave form of the 128-row kernel on grids of up to
+// two / one workgroup(s) per CU; everywhere else the 128-row kernel is fastest.
 int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal) {
   (void)is_causal;
   const int v = fa_resolve_variant(dtype, D);
   if (v != FA_VARIANT_MFMA) return v;
-  const long long blocks256 = (long long)B * H * ((N + 255) / 256);
-  if (D == 128 && N >= 4096 && blocks256 >= 512 && fa::pp_supported(dtype, D)) return FA_VARIANT_MFMA_PP;
+  // (round 2 sent long head_dim-128 sequences to the paired-block kernel; since the 128-row kernel stages its tiles by
+  // LDS-DMA it is 8-10 % ahead there too -- config 4 shard 1295 vs 1181 TFLOP/s, profiles/r03/ab_dma_late_and_d128_auto.log --
+  // and FA_VARIANT_MFMA_PP is reachable by name only)
   // small grids: fewer 128-row workgroups than a quarter of the CUs (or half, when each would walk >= 32 tiles):
   // split the keys of every 32-row block over the waves of a workgroup instead (config 2: 15.9 -> 10.6 us)
   const long long blocks128 = (long long)B * H * ((N + 127) / 128);

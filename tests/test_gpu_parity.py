@@ -547,8 +547,7 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
         (2, 3, 64, 64, "f16", True, "mfma"),               # N <= 64: a single tile, never split-KV
         (1, 2, 4096, 128, "bf16", True, "mfma_splitkv"),   # head_dim 128, 64 blocks
         (1, 16, 2048, 128, "bf16", True, "mfma_split2"),   # 256 blocks of 128 rows, N < 4096
-        (1, 32, 4096, 128, "bf16", True, "mfma_pp"),       # 512 blocks of 256 rows, N >= 4096: the paired-block kernel
-        (1, 31, 4096, 128, "bf16", True, "mfma"),          # 496 blocks of 256 rows: below the paired-block rule
+        (1, 32, 4096, 128, "bf16", True, "mfma"),          # long head_dim-128 sequences: the 128-row kernel (round 2: paired-block)
         (1, 4, 300, 96, "bf16", True, "mfma"),             # head dims only the 128-row kernel has
         (1, 8, 1024, 64, "fp8", True, "mfma_splitkv"),
         (1, 40, 1024, 64, "fp8", True, "mfma"),
@@ -653,8 +652,8 @@ def test_config4_sharded_equals_unsharded_bit_for_bit(fa, oracle_mod, variant):
     # BASELINE configs[3] shards (batch, head) over 8 GPUs. The shards must be the SAME computation: here the
     # 8 shards of a reduced-batch config-4 tensor (B=8 -> 8 shards of 2 heads each, N=4096, D=128, bf16 causal) are
     # computed one by one on this GPU (as 8 ranks would, flash_attention_metal_amd.shard.shard_heads) and compared bit
-    # for bit with the unsharded call. The kernel is named explicitly: config 4 itself runs "mfma_pp" on every rank
-    # (32 heads x 64 blocks per GPU), but "auto" on this reduced problem would pick by grid size.
+    # for bit with the unsharded call. The kernels are named explicitly ("auto" on this reduced problem would pick by grid
+    # size); config 4 itself runs "mfma" on every rank.
     import torch
 
     from flash_attention_metal_amd.shard import shard_heads
@@ -670,7 +669,7 @@ def test_config4_sharded_equals_unsharded_bit_for_bit(fa, oracle_mod, variant):
                                               is_causal=True, variant=variant)
         assert torch.equal(o_r[0], o_all.view(B * H, N, D)[lo:hi]) and torch.equal(l_r[0], l_all.view(B * H, N)[lo:hi])
     lib = fa.load_library()  # and the real config 4 resolves to the same kernel sharded or not
-    assert lib.fa_resolve_variant_for(2, 128, 8, 32, 16384, 1) == lib.fa_resolve_variant_for(2, 128, 1, 32, 16384, 1) == fa.VARIANTS["mfma_pp"]
+    assert lib.fa_resolve_variant_for(2, 128, 8, 32, 16384, 1) == lib.fa_resolve_variant_for(2, 128, 1, 32, 16384, 1) == fa.VARIANTS["mfma"]
     torch.cuda.synchronize()
 
 
