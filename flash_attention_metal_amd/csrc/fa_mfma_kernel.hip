@@ -48,9 +48,6 @@
 #define FA_MFMA_DMA 1  // 1 (f16/bf16, head_dim 32/64/128): K/V tiles go global -> LDS by LDS-DMA (buffer_load ... lds), no staging registers, no
                        // ds_write: config 3 +6.7 %, head_dim 128 +9..11 %, bit-identical outputs (profiles/r03/ab_mfma_lds_dma.log); 0 = register staging
 #endif
-#ifndef FA_DMA_LATE
-#define FA_DMA_LATE 0
-#endif
 #ifndef FA_LAK
 #define FA_LAK (D == 128 ? 4 : 2)  // head dims other than 64: K fragments are read this many MFMAs ahead of their use (head_dim 128: 4 since the
 #endif                             // LDS-DMA staging freed the registers: +1..2 %, profiles/r03/ab_dma_knobs.log)
@@ -251,12 +248,32 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lv), "v"(dma_vvo), "s"(rv), "s"(soff) : "memory");
     }
   };
+  // fp8 inputs: the K tile stays raw e4m3 in LDS (rows of D bytes), so IT can travel by LDS-DMA; V is widened to bf16 on the way
+  // and keeps the register path
+  constexpr bool DMA_K8 = (FA_MFMA_DMA != 0) && IS_FP8;
+  constexpr int RPP8 = 1024 / KRB, NPW8 = (BN / RPP8) / RW;  // rows per piece / pieces per wave of an e4m3 K tile
+  unsigned dma_k8o = 0;
+  if constexpr (DMA_K8) {
+    static_assert((RW * RPP8) % 16 == 0 && NPW8 >= 1, "the piece stride must keep the swizzle");
+    constexpr int CPR8 = KRB / 16;
+    const int row = wave * RPP8 + lane / CPR8, pc = lane % CPR8;
+    const int skx8 = (D == 64) ? ((row >> 2) & 3) : (D == 128) ? ((row >> 1) & 7) : (row & 15);
+    dma_k8o = (unsigned)(row * GRB + ((pc ^ skx8) << 4));
+  }
+  auto stage_dma_k8 = [&](int t, int buf) {
+#pragma unroll
+    for (int j = 0; j < NPW8; ++j) {
+      const unsigned soff = (unsigned)t * GTILE + j * (RW * 1024);
+      const unsigned lk = (unsigned)(__UINTPTR_TYPE__)Kbuf + buf * KTILE + (wave + RW * j) * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dma_k8o), "s"(rk), "s"(soff) : "memory");
+    }
+  };
   u32x4 kst[NCH], vst[NCH];
   auto stage_load = [&](int t) {
     const unsigned g0 = (unsigned)t * GTILE;  // tile t starts at key t*BN
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, g0 + st_g[i], 0, 0);
+      if constexpr (!DMA_K8) kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, g0 + st_g[i], 0, 0);
       vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, g0 + st_g[i], 0, 0);
     }
   };
@@ -264,7 +281,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       if constexpr (IS_FP8) {  // K: raw e4m3; V: e4m3 -> bf16 is exact, 16 elements = two bf16 chunks
-        lds_write_b128(Kbuf + buf * KTILE + st_k[i], kst[i]);
+        if constexpr (!DMA_K8) lds_write_b128(Kbuf + buf * KTILE + st_k[i], kst[i]);
         lds_write_b128(Vbuf + buf * TILE + st_v[i], fp8x8_to_bf16(u32x2{vst[i][0], vst[i][1]}));
         lds_write_b128(Vbuf + buf * TILE + st_v1[i], fp8x8_to_bf16(u32x2{vst[i][2], vst[i][3]}));
       } else {
@@ -296,8 +313,10 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
     stage_dma(sp, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
+    if constexpr (DMA_K8) stage_dma_k8(sp, 0);
     stage_load(sp);  // this split's first tile (past the end of a short head: zeros through the descriptor, never used)
     stage_write(0);
+    if constexpr (DMA_K8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // Retire the Q-fragment loads HERE: hipcc's waitcnt pass otherwise carries them into the
   // loop as "possibly pending" and drains vmcnt(0) in front of every tile's first MFMAs, i.e.
@@ -360,11 +379,11 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   auto tile = [&](auto bufc, const int t) {
     constexpr int buf = decltype(bufc)::value;
     const int kv0 = t * BN;
-    constexpr bool DMA_LATE = DMA && (FA_DMA_LATE != 0);  // issue the LDS-DMA pieces behind the score MFMAs instead of in front of them
-    if (t + SPLIT < nT) {  // this split's next tile, in flight under this tile's MFMAs
-      if constexpr (DMA) {
-        if constexpr (!DMA_LATE) stage_dma(t + SPLIT, buf ^ 1);
+    if (t + SPLIT < nT) {  // this split's next tile, in flight under this tile's MFMAs (issuing the LDS-DMA pieces behind the score
+      if constexpr (DMA) {  // MFMAs instead was measured: -29 % on causal shapes, profiles/r03/ab_dma_late_and_d128_auto.log)
+        stage_dma(t + SPLIT, buf ^ 1);
       } else {
+        if constexpr (DMA_K8) stage_dma_k8(t + SPLIT, buf ^ 1);
         stage_load(t + SPLIT);
       }
     }
@@ -456,9 +475,6 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
           if (i + LA < NK) kread(i + LA);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
-      if constexpr (DMA_LATE) {
-        if (t + SPLIT < nT) stage_dma(t + SPLIT, buf ^ 1);
       }
       // ---- mask (only on tiles that cross the diagonal or the end of the sequence)
       const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk);
@@ -614,12 +630,13 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
         }
       }
     }
-    if constexpr (DMA_LATE) {  // a wave that skipped the tile (causal) still moves its pieces
-      if (!wave_active && t + SPLIT < nT) stage_dma(t + SPLIT, buf ^ 1);
-    }
     if (t + SPLIT < nT) {
-      if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued during this tile have landed
-      else stage_write(buf ^ 1);
+      if constexpr (DMA) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this tile have landed
+      } else {
+        stage_write(buf ^ 1);
+        if constexpr (DMA_K8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     __syncthreads();
   };
