@@ -225,11 +225,16 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     evs0 = make_events(torch, stream, args.steps)
-    barrier()
-    t0 = time.perf_counter()
-    blocks, evs = timed_launches(torch, stream, step, args.steps, evs=evs0)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # The timed region runs twice: once as the tail of the warm-up (same calls, result discarded), then for the record. The
+    # FIRST pass of this code in a process spends ~0.12 ms of host time in its first event record (per-statement timestamps:
+    # 127 us against 2-10 us for every later one), 4-5 % of the driver's 2.8 ms region; the second pass is clean
+    # (wall - events: 154 -> 34 us).
+    for rehearsal_pass in (True, False):
+        barrier()
+        t0 = time.perf_counter()
+        blocks, evs = timed_launches(torch, stream, step, args.steps, evs=evs0)
+        barrier()
+        elapsed = time.perf_counter() - t0
     kern_ms = sorted(a.elapsed_time(b) / (hi_i - lo_i) for (lo_i, hi_i), (a, b) in zip(blocks, evs))
     launches_total = sum(a.elapsed_time(b) for a, b in evs)  # ms over all K launches
     flops_step_rank = fa.algorithmic_flops(1, my, N, D, CAUSAL)
