@@ -51,15 +51,30 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef FA_BWD_DMA
 #define FA_BWD_DMA 1  // 1: the streamed tiles go global -> LDS by LDS-DMA (buffer_load ... lds; the chunk swizzle sits on the source address):
 #endif                // no staging registers, no ds_write_b128 (as in the forward kernels, profiles/r03/ab_mfma_lds_dma.log); 0 = register staging
-#ifndef FA_BWD_SUB
-#define FA_BWD_SUB 2  // 64-row sub-tiles per staged tile: one barrier and one staging pass per FA_BWD_SUB * 64 keys (dQ) / queries (dK, dV)
+#ifndef FA_BWD_LA
+#define FA_BWD_LA 2  // dK/dV kernel: row fragments are read this many MFMAs ahead of their use
 #endif
-constexpr int BSUB = FA_BWD_SUB;
-constexpr int BT = BSUB * BN;  // rows of a staged tile
+#ifndef FA_BWD_LA2
+#define FA_BWD_LA2 2  // dK/dV kernel: the same for the transposed fragments
+#endif
+#ifndef FA_BWD_OCC
+#define FA_BWD_OCC 3  // workgroups per CU the head_dim-64 dK/dV kernel is compiled for (register cap 168)
+#endif
+// 64-row sub-tiles per staged tile: one barrier and one staging pass per SUB * 64 keys (dQ) / queries (dK, dV)
+#ifndef FA_BWD_SUB
+#define FA_BWD_SUB 2
+#endif
+#ifndef FA_BWD_SUB_KV64
+#define FA_BWD_SUB_KV64 1  // head_dim-64 dK/dV kernel: 34 KiB of LDS per workgroup, three workgroups per CU
+#endif
+constexpr int bwd_sub_dq(int D) { return FA_BWD_SUB; }
+constexpr int bwd_sub_kv(int D) { return D == 64 ? FA_BWD_SUB_KV64 : FA_BWD_SUB; }
 
 // per-head-dim constants of the kernels below (the reference kernel is head_dim 64 only, kernels.metal:905-1265;
 // 128 is the same algorithm with twice the k-steps / output blocks and one workgroup per CU)
-#define FA_BWD_CONSTS(D)                                                                         \
+#define FA_BWD_CONSTS(D, SUBS)                                                                   \
+  constexpr int BSUB = (SUBS);     /* sub-tiles per staged tile */                               \
+  constexpr int BT = BSUB * BN;    /* rows of a staged tile */                                   \
   constexpr int BD = (D);          /* head dim */                                                \
   constexpr int BRB = BD * 2;      /* row bytes */                                               \
   constexpr int BCPR = BD / 8;     /* 16-byte chunks per row */                                  \
@@ -84,14 +99,14 @@ constexpr int BT = BSUB * BN;  // rows of a staged tile
     const int row = wave_ * RPP + lane_ / BCPR, pc = lane_ % BCPR;                            \
     return (unsigned)(row * BRB + ((pc ^ u_swz(row)) << 4));                                  \
   };                                                                                          \
-  (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)STILE; (void)u_swz; (void)tr_off; (void)NTV; (void)RPP; (void)NPW; (void)dma_off
+  (void)BT; (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)STILE; (void)u_swz; (void)tr_off; (void)NTV; (void)RPP; (void)NPW; (void)dma_off
 
 // ---------------------------------------------------------------------------
 // dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
 // ---------------------------------------------------------------------------
 template <typename Tag, int D, bool CAUSAL>
 __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(BwdParams p) {
-  FA_BWD_CONSTS(D);
+  FA_BWD_CONSTS(D, bwd_sub_dq(D));
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -316,8 +331,8 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
 // dK, dV: workgroup = 128 keys, wave = 32 keys (key on the lane, queries in the registers)
 // ---------------------------------------------------------------------------
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(BwdParams p) {
-  FA_BWD_CONSTS(D);
+__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : 1)) void bwd_dkdv_kernel(BwdParams p) {
+  FA_BWD_CONSTS(D, bwd_sub_kv(D));
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -351,15 +366,21 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
   const float c2 = p.scale * LOG2E;
 
   const int kx = u_swz(r);
-  int koff[BKS];
+  const unsigned qu0 = (unsigned)(__UINTPTR_TYPE__)QU;
+  unsigned koff[BKS];  // ABSOLUTE LDS addresses in the current Q buffer (the dO image is 2 STILE further)
 #pragma unroll
-  for (int ks = 0; ks < BKS; ++ks) koff[ks] = r * BRB + (((2 * ks + h) ^ kx) << 4);
+  for (int ks = 0; ks < BKS; ++ks) koff[ks] = qu0 + r * BRB + (((2 * ks + h) ^ kx) << 4);
   const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
-  int voff[NTV][BDB];
+  unsigned voff[NTV][BDB];
 #pragma unroll
   for (int tv = 0; tv < NTV; ++tv)
 #pragma unroll
-    for (int db = 0; db < BDB; ++db) voff[tv][db] = tr_off(tv, db, h, g1, vq, vp);
+    for (int db = 0; db < BDB; ++db) voff[tv][db] = qu0 + tr_off(tv, db, h, g1, vq, vp);
+  // Offsets INCLUDING the current buffer's: with the buffer base added at the point of use hipcc kept a second, per-tile copy
+  // of all twelve (base + offset) in registers (seen in the ISA, and spilled under the 168-register cap); they flip in place
+  unsigned rowoff = (unsigned)(__UINTPTR_TYPE__)ROWS + 4 * h * 4;
+  int flip = STILE, flip_rows = 2 * BT * 4;  // to the other buffer and back
+  auto at = [](unsigned a) { return (const lds_char *)(__UINTPTR_TYPE__)a; };
   constexpr int NCH = BT * BCPR / NTHREADS;
   int st_g[NCH], st_r[NCH];
 #pragma unroll
@@ -378,7 +399,8 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
   // here makes hipcc wait for it -- vmcnt(0), i.e. for the whole tile's loads issued just before -- at the top of every
   // iteration (seen in the ISA: the memory latency was exposed once per tile). It is scaled / negated in stage_write.
   float rowv = 0.0f;
-  const float *row_src = (tid < BT ? p.lse : p.delta) + (long long)bh * p.N;
+  // (2 BT threads = whole waves: the choice of array is wave-uniform and stays in scalar registers)
+  const float *row_src = (__builtin_amdgcn_readfirstlane(tid) < BT ? p.lse : p.delta) + (long long)bh * p.N;
   constexpr bool DMA = FA_BWD_DMA != 0;
   const unsigned dvo = dma_off(wave, lane);
   auto stage_load = [&](int t, int buf) {
@@ -443,104 +465,115 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dkdv_kernel(B
     if (t + 1 < nTq) stage_load(t + 1, buf ^ 1);
 #pragma unroll
     for (int sub = 0; sub < BSUB; ++sub) {
+    const int sub_c = sub;
     const int qt0 = t * BT + sub * BN;
     if (qt0 < p.N && (!CAUSAL || qt0 + BN - 1 >= kw0)) {  // some query of the sub-tile sees this wave's first key
-      const lds_char *Qr = QU + buf * STILE + sub * BTILE, *Qt = Qr, *Or = OU + buf * STILE + sub * BTILE, *Ot = Or;
-      const lds_char *rows = ROWS + buf * (2 * BT * 4) + sub * (BN * 4);
-      f32x16 s[2], dp[2];
-      __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
-      // the chains start from the row constants: registers 4g..4g+3 of block qb are query rows 32qb + 8g + 4h + 0..3 of the tile
+      // (the buffer's offset is inside koff / voff / rowoff, toggled once per tile: everything added here is an immediate)
+      const int QS = sub_c * BTILE, OS = 2 * STILE + sub_c * BTILE;  // Q / dO sub-tile images, relative to koff / voff
+      const unsigned rows = rowoff + sub_c * (BN * 4);
+      // only sub-tiles that cross the diagonal for this wave need the per-element mask (wave-uniform)
+      const bool need_mask = CAUSAL && (qt0 < kw0 + WM - 1);
+      // One 32-query half (qb) at a time -- scores, P / dS, then its share of dV / dK -- so that only ONE score and ONE dP tuple
+      // are live (round 3 first kept both halves': 212 VGPR, two waves per SIMD; this form fits three).
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16 sq, dpq;
+        __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
+        // the chains start from the row constants: registers 4g..4g+3 are query rows 32qb + 8g + 4h + 0..3 of the sub-tile
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int ql = 32 * qb + 8 * g + 4 * h;
-          const u32x4 l4 = lds_read_b128(rows + ql * 4);
-          const u32x4 d4 = lds_read_b128(rows + BT * 4 + ql * 4);
+          const int ql = 32 * qb + 8 * g;  // (+ 4h: in rowoff)
+          const u32x4 l4 = lds_read_b128(at(rows + ql * 4));
+          const u32x4 d4 = lds_read_b128(at(rows + BT * 4 + ql * 4));
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             // (scalar temporaries on purpose: __builtin_bit_cast applied directly to the vector element expression
             //  l4[e] read element 0 for every e -- seen in the IR)
             const unsigned lw = l4[e], dw = d4[e];
-            s[qb][4 * g + e] = __builtin_bit_cast(float, lw);
-            dp[qb][4 * g + e] = __builtin_bit_cast(float, dw);
+            sq[4 * g + e] = __builtin_bit_cast(float, lw);
+            dpq[4 * g + e] = __builtin_bit_cast(float, dw);
           }
         }
-      {
-        constexpr int NF = 4 * BKS, LA = 4;
-        vec8 fr[NF];
-        auto fread = [&](int f) {  // f = (qb, ks, which): which 0 = Q row fragment, 1 = dO row fragment
-          const int qb = f / (2 * BKS), ks = (f / 2) % BKS;
-          fr[f] = __builtin_bit_cast(vec8, lds_read_b128(((f & 1) ? Or : Qr) + qb * 32 * BRB + koff[ks]));
+        {
+          constexpr int NF = 2 * BKS, LA = FA_BWD_LA;
+          vec8 fr[NF];
+          auto fread = [&](int f) {  // f = (ks, which): which 0 = Q row fragment, 1 = dO row fragment
+            fr[f] = __builtin_bit_cast(vec8, lds_read_b128(at(koff[f / 2] + ((f & 1) ? OS : QS) + qb * 32 * BRB)));
+          };
+#pragma unroll
+          for (int f = 0; f < LA; ++f) fread(f);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int f = 0; f < NF; ++f) {
+            if (f & 1) dpq = M::mfma(fr[f], vf[f / 2], dpq);
+            else sq = M::mfma(fr[f], kf[f / 2], sq);
+            if (f + LA < NF) fread(f + LA);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // dV / dK fragments of this half (step j = (st, db, which): which 0 = dO^T fragment -> dV, 1 = Q^T fragment -> dK) are
+        // read LA2 steps ahead of their MFMA, the first ones before the P / dS arithmetic (they do not depend on it)
+        constexpr int NJ = 4 * BDB, LA2 = FA_BWD_LA2, TV = BD == 64 ? 4 : 2;
+        s16x4 tlo[NJ], thi[NJ];
+        auto tread = [&](int j) {
+          const int jj = j / 2, R0 = 32 * qb + 16 * (jj / BDB), db = jj % BDB;
+          const int src = (j & 1) ? QS : OS;
+          tlo[j] = lds_read_tr16(at(voff[(R0 >> 3) % TV][db] + src + R0 * BRB));
+          thi[j] = lds_read_tr16(at(voff[((R0 >> 3) + 1) % TV][db] + src + (R0 + 8) * BRB));
         };
 #pragma unroll
-        for (int f = 0; f < LA; ++f) fread(f);
+        for (int j = 0; j < LA2; ++j) tread(j);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const int qb = f / (2 * BKS), ks = (f / 2) % BKS;
-          if (f & 1) dp[qb] = M::mfma(fr[f], vf[ks], dp[qb]);
-          else s[qb] = M::mfma(fr[f], kf[ks], s[qb]);
-          if (f + LA < NF) fread(f + LA);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // dV / dK fragments (step j = (qb, st, db, which): which 0 = dO^T fragment -> dV, 1 = Q^T fragment -> dK) are read LA2
-      // steps ahead of their MFMA, the first ones before the P / dS arithmetic (they do not depend on it)
-      constexpr int NJ = 8 * BDB, LA2 = 4, TV = BD == 64 ? 4 : 2;
-      s16x4 tlo[NJ], thi[NJ];
-      auto tread = [&](int j) {
-        const int jj = j / 2, R0 = 32 * (jj / (2 * BDB)) + 16 * ((jj / BDB) % 2), db = jj % BDB;
-        const lds_char *src = (j & 1) ? Qt : Ot;
-        tlo[j] = lds_read_tr16(src + R0 * BRB + voff[(R0 >> 3) % TV][db]);
-        thi[j] = lds_read_tr16(src + (R0 + 8) * BRB + voff[((R0 >> 3) + 1) % TV][db]);
-      };
-#pragma unroll
-      for (int j = 0; j < LA2; ++j) tread(j);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(0);
-      // registers 4g..4g+3 of block qb are query rows 32qb + 8g + 4h + 0..3 of the tile
-      vec8 pf[2][2], df[2][2];
-      // only tiles that cross the diagonal for this wave need the per-element mask (wave-uniform)
-      const bool need_mask = CAUSAL && (qt0 < kw0 + WM - 1);
-      if (need_mask) {  // key > query (kernels.metal:748): S' = -inf there. A wave-uniform BRANCH: written as a per-element
-#pragma unroll          // condition hipcc turned it into 32 compare + select pairs on every tile (seen in the ISA)
-        for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
+        __builtin_amdgcn_s_setprio(0);
+        if (need_mask) {  // key > query (kernels.metal:748): S' = -inf there. A wave-uniform BRANCH: written as a per-element
+#pragma unroll            // condition hipcc turned it into 32 compare + select pairs on every tile (seen in the ISA)
           for (int i = 0; i < 16; ++i)
-            s[qb][i] = (qt0 + 32 * qb + 8 * (i >> 2) + 4 * h + (i & 3) < krow) ? -INFINITY : s[qb][i];
-      }
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+            sq[i] = (qt0 + 32 * qb + 8 * (i >> 2) + 4 * h + (i & 3) < krow) ? -INFINITY : sq[i];
+        }
+        vec8 pf[2], df[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const float pv = __builtin_amdgcn_exp2f(s[qb][i]);  // S' = Q.K~ - lse*log2e came out of the matrix core
-          s[qb][i] = pv;
-          dp[qb][i] = pv * dp[qb][i];  // dS (without the softmax scale: it goes onto the finished dK)
+          const float pv = __builtin_amdgcn_exp2f(sq[i]);  // S' = Q.K~ - lse*log2e came out of the matrix core
+          sq[i] = pv;
+          dpq[i] = pv * dpq[i];  // dS (without the softmax scale: it goes onto the finished dK)
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            pf[qb][st][j] = (elem)s[qb][8 * st + j];
-            df[qb][st][j] = (elem)dp[qb][8 * st + j];
+            pf[st][j] = (elem)sq[8 * st + j];
+            df[st][j] = (elem)dpq[8 * st + j];
           }
-      }
-      // dV^T += dO^T.P ; dK^T += Q^T.dS   (reduction over the tile's 64 query rows)
-      __builtin_amdgcn_s_setprio(1);
-      {
+        // dV^T += dO^T.P ; dK^T += Q^T.dS   (reduction over this half's 32 query rows)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int jj = j / 2, qb = jj / (2 * BDB), st = (jj / BDB) % 2, db = jj % BDB;
+          const int jj = j / 2, st = jj / BDB, db = jj % BDB;
           const s16x8 a8 = __builtin_shufflevector(tlo[j], thi[j], 0, 1, 2, 3, 4, 5, 6, 7);
-          if (j & 1) dkacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), df[qb][st], dkacc[db]);
-          else dvacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), pf[qb][st], dvacc[db]);
+          if (j & 1) dkacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), df[st], dkacc[db]);
+          else dvacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), pf[st], dvacc[db]);
           if (j + LA2 < NJ) tread(j + LA2);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
     }  // sub-tiles
+#pragma unroll
+    for (int ks = 0; ks < BKS; ++ks) {
+      koff[ks] += flip;
+      asm volatile("" : "+v"(koff[ks]));
+    }
+#pragma unroll
+    for (int tv = 0; tv < NTV; ++tv)
+#pragma unroll
+      for (int db = 0; db < BDB; ++db) {
+        voff[tv][db] += flip;
+        asm volatile("" : "+v"(voff[tv][db]));
+      }
+    rowoff += flip_rows;
+    asm volatile("" : "+v"(rowoff));
+    flip = -flip;
+    flip_rows = -flip_rows;
     if (t + 1 < nTq) stage_write(buf ^ 1, t + 1);
     __syncthreads();
   }
@@ -565,7 +598,7 @@ template <typename Tag, int D, bool CAUSAL>
 static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
   constexpr int BTILE = BN * D * 2;
   const int nB = (p.N + BM - 1) / BM;
-  const size_t smem_dq = 4 * BSUB * BTILE, smem_kv = 4 * BSUB * BTILE + 2 * 2 * BT * 4;
+  const size_t smem_dq = 4 * bwd_sub_dq(D) * BTILE, smem_kv = 4 * bwd_sub_kv(D) * BTILE + 2 * 2 * bwd_sub_kv(D) * BN * 4;
   auto kq = bwd_dq_kernel<Tag, D, CAUSAL>;
   auto kk = bwd_dkdv_kernel<Tag, D, CAUSAL>;
   hipError_t e = hipSuccess;

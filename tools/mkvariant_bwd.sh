@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build a variant of libfa_mi355.so whose BACKWARD kernels carry extra -D flags, into tools/ab/lib_<name>.so (for tools/ab_bwd.py).
+# The other objects are the ones already built in csrc/ (run make there first).
+# usage: tools/mkvariant_bwd.sh <name> "<extra flags>"
+set -e
+name=$1; shift
+extra="$*"
+root=$(cd "$(dirname "$0")/.." && pwd)
+src=$root/flash_attention_metal_amd/csrc
+out=$root/tools/ab
+mkdir -p $out/obj_$name
+for f in fa_api fa_scalar_kernels fa_mfma_kernel fa_fwd_pp_kernel fa_fwd_splitkv_kernel; do cp $src/$f.o $out/obj_$name/$f.o; done
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -fno-honor-nans $extra \
+  -c $src/fa_bwd_kernels.hip -o $out/obj_$name/fa_bwd_kernels.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/lib_$name.so $out/obj_$name/*.o
+rm -rf $out/obj_$name
+echo built $out/lib_$name.so
