@@ -52,10 +52,13 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define FA_BWD_DMA 1  // 1: the streamed tiles go global -> LDS by LDS-DMA (buffer_load ... lds; the chunk swizzle sits on the source address):
 #endif                // no staging registers, no ds_write_b128 (as in the forward kernels, profiles/r03/ab_mfma_lds_dma.log); 0 = register staging
 #ifndef FA_BWD_LA
-#define FA_BWD_LA 2  // dK/dV kernel: row fragments are read this many MFMAs ahead of their use
+#define FA_BWD_LA 3  // dK/dV kernel: row fragments are read this many MFMAs ahead of their use
 #endif
 #ifndef FA_BWD_LA2
 #define FA_BWD_LA2 2  // dK/dV kernel: the same for the transposed fragments
+#endif
+#ifndef FA_BWD_OCC_DQ
+#define FA_BWD_OCC_DQ 3  // the same for the dQ kernel
 #endif
 #ifndef FA_BWD_OCC
 #define FA_BWD_OCC 3  // workgroups per CU the head_dim-64 dK/dV kernel is compiled for (register cap 168)
@@ -67,7 +70,16 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef FA_BWD_SUB_KV64
 #define FA_BWD_SUB_KV64 1  // head_dim-64 dK/dV kernel: 34 KiB of LDS per workgroup, three workgroups per CU
 #endif
-constexpr int bwd_sub_dq(int D) { return FA_BWD_SUB; }
+#ifndef FA_BWD_SUB_DQ64
+#define FA_BWD_SUB_DQ64 1
+#endif
+#ifndef FA_BWD_SUB_DQ128
+#define FA_BWD_SUB_DQ128 1
+#endif
+#ifndef FA_BWD_OCC_DQ128
+#define FA_BWD_OCC_DQ128 2  // head_dim-128 dQ kernel: 64 KiB of LDS and at most 256 registers -> two workgroups per CU
+#endif
+constexpr int bwd_sub_dq(int D) { return D == 64 ? FA_BWD_SUB_DQ64 : FA_BWD_SUB_DQ128; }
 constexpr int bwd_sub_kv(int D) { return D == 64 ? FA_BWD_SUB_KV64 : FA_BWD_SUB; }
 
 // per-head-dim constants of the kernels below (the reference kernel is head_dim 64 only, kernels.metal:905-1265;
@@ -105,7 +117,7 @@ constexpr int bwd_sub_kv(int D) { return D == 64 ? FA_BWD_SUB_KV64 : FA_BWD_SUB;
 // dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
 // ---------------------------------------------------------------------------
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(BwdParams p) {
+__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC_DQ : FA_BWD_OCC_DQ128)) void bwd_dq_kernel(BwdParams p) {
   FA_BWD_CONSTS(D, bwd_sub_dq(D));
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
@@ -162,15 +174,20 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
   asm volatile("" : "+v"(nlse), "+v"(ndlt));  // opaque: else hipcc re-materialises the splats in front of every MFMA
 
   const int kx = u_swz(r);
-  int koff[BKS];
+  // ABSOLUTE LDS addresses in the current K buffer (the V image is 2 STILE further), flipped in place once per tile: with the
+  // buffer base added at the point of use hipcc kept a second, per-tile copy of all (base + offset) in registers (seen in the ISA)
+  const unsigned ku0 = (unsigned)(__UINTPTR_TYPE__)KU;
+  int flip = STILE;
+  auto at = [](unsigned a) { return (const lds_char *)(__UINTPTR_TYPE__)a; };
+  unsigned koff[BKS];
 #pragma unroll
-  for (int ks = 0; ks < BKS; ++ks) koff[ks] = r * BRB + (((2 * ks + h) ^ kx) << 4);
+  for (int ks = 0; ks < BKS; ++ks) koff[ks] = ku0 + r * BRB + (((2 * ks + h) ^ kx) << 4);
   const int g1 = (lane >> 4) & 1, vq = (lane >> 2) & 3, vp = lane & 3;
-  int voff[NTV][BDB];
+  unsigned voff[NTV][BDB];
 #pragma unroll
   for (int tv = 0; tv < NTV; ++tv)
 #pragma unroll
-    for (int db = 0; db < BDB; ++db) voff[tv][db] = tr_off(tv, db, h, g1, vq, vp);
+    for (int db = 0; db < BDB; ++db) voff[tv][db] = ku0 + tr_off(tv, db, h, g1, vq, vp);
   constexpr int NCH = BT * BCPR / NTHREADS;
   int st_g[NCH], st_r[NCH];
 #pragma unroll
@@ -242,74 +259,82 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? 2 : 1)) void bwd_dq_kernel(Bwd
     for (int sub = 0; sub < BSUB; ++sub) {
     const int kv0 = t * BT + sub * BN;
     if (kv0 < kv_end && (!CAUSAL || kv0 <= qw0 + WM - 1)) {
-      const lds_char *Kr = KU + buf * STILE + sub * BTILE, *Kt = Kr, *Vr = VR + buf * STILE + sub * BTILE;
-      f32x16 s[2], dp[2];
-      __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
-      {
-        // 4 BKS row fragments (K and V alternating), each read LA products ahead of the MFMA that consumes it
-        constexpr int NF = 4 * BKS, LA = 4;
-        vec8 fr[NF];
-        auto fread = [&](int f) {  // f = (kb, ks, which): which 0 = K row fragment, 1 = V row fragment
-          const int kb = f / (2 * BKS), ks = (f / 2) % BKS;
-          fr[f] = __builtin_bit_cast(vec8, lds_read_b128(((f & 1) ? Vr : Kr) + kb * 32 * BRB + koff[ks]));
-        };
+      const int KS = sub * BTILE, VS = 2 * STILE + sub * BTILE;  // K / V sub-tile images, relative to koff / voff
+      const bool need_mask = CAUSAL && (kv0 + BN - 1 > qw0);
+      // One 32-key half (kb) at a time -- scores, dS, then its share of dQ -- so that only one score and one dP tuple are live
 #pragma unroll
-        for (int f = 0; f < LA; ++f) fread(f);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 sk, dpk;
+        __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
+        {
+          // 2 BKS row fragments (K and V alternating), each read LA products ahead of the MFMA that consumes it
+          constexpr int NF = 2 * BKS, LA = FA_BWD_LA;
+          vec8 fr[NF];
+          auto fread = [&](int f) {  // f = (ks, which): which 0 = K row fragment, 1 = V row fragment
+            fr[f] = __builtin_bit_cast(vec8, lds_read_b128(at(koff[f / 2] + ((f & 1) ? VS : KS) + kb * 32 * BRB)));
+          };
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const int kb = f / (2 * BKS), ks = (f / 2) % BKS;
-          if (f & 1) dp[kb] = M::mfma(fr[f], dof[ks], ks == 0 ? ndlt : dp[kb]);
-          else s[kb] = M::mfma(fr[f], qf[ks], ks == 0 ? nlse : s[kb]);
-          if (f + LA < NF) fread(f + LA);
+          for (int f = 0; f < LA; ++f) fread(f);
           __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      if (CAUSAL && (kv0 + BN - 1 > qw0)) {  // key > query -> masked (kernels.metal:748)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const int lim = qrow - kv0 - 32 * kb - 4 * h;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) s[kb][i] = ((i & 3) + 8 * (i >> 2) > lim) ? -INFINITY : s[kb][i];
+          for (int f = 0; f < NF; ++f) {
+            const int ks = f / 2;
+            if (f & 1) dpk = M::mfma(fr[f], dof[ks], ks == 0 ? ndlt : dpk);
+            else sk = M::mfma(fr[f], qf[ks], ks == 0 ? nlse : sk);
+            if (f + LA < NF) fread(f + LA);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
-      }
-      // dQ^T += K^T.dS^T : step j = (kb, st, db); the transposed K fragments are read LA2 steps ahead of their MFMA, the first
-      // ones before the dS arithmetic (they do not depend on it)
-      {
-        constexpr int NJ = 4 * BDB, LA2 = 4, TV = BD == 64 ? 4 : 2;
+        // dQ^T += K^T.dS^T : step j = (st, db); the transposed K fragments are read LA2 steps ahead of their MFMA, the first
+        // ones before the dS arithmetic (they do not depend on it)
+        constexpr int NJ = 2 * BDB, LA2 = FA_BWD_LA2, TV = BD == 64 ? 4 : 2;
         s16x4 tlo[NJ], thi[NJ];
         auto tread = [&](int j) {
-          const int R0 = 32 * (j / (2 * BDB)) + 16 * ((j / BDB) % 2), db = j % BDB;
-          tlo[j] = lds_read_tr16(Kt + R0 * BRB + voff[(R0 >> 3) % TV][db]);
-          thi[j] = lds_read_tr16(Kt + (R0 + 8) * BRB + voff[((R0 >> 3) + 1) % TV][db]);
+          const int R0 = 32 * kb + 16 * (j / BDB), db = j % BDB;
+          tlo[j] = lds_read_tr16(at(voff[(R0 >> 3) % TV][db] + KS + R0 * BRB));
+          thi[j] = lds_read_tr16(at(voff[((R0 >> 3) + 1) % TV][db] + KS + (R0 + 8) * BRB));
         };
 #pragma unroll
         for (int j = 0; j < LA2; ++j) tread(j);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
+        if (need_mask) {  // key > query -> masked (kernels.metal:748); a wave-uniform branch
+          const int lim = qrow - kv0 - 32 * kb - 4 * h;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sk[i] = ((i & 3) + 8 * (i >> 2) > lim) ? -INFINITY : sk[i];
+        }
         // dS^T = P^T o (dP^T - delta) (the softmax scale goes onto the finished dQ): keys in the registers, the query on the lane
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int i = 0; i < 16; ++i) sk[i] = __builtin_amdgcn_exp2f(sk[i]) * dpk[i];
+        vec8 df[2];
 #pragma unroll
-          for (int i = 0; i < 16; ++i) s[kb][i] = __builtin_amdgcn_exp2f(s[kb][i]) * dp[kb][i];
-        vec8 df[2][2];
+        for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) df[kb][st][j] = (elem)s[kb][8 * st + j];
+          for (int j = 0; j < 8; ++j) df[st][j] = (elem)sk[8 * st + j];
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const s16x8 k8 = __builtin_shufflevector(tlo[j], thi[j], 0, 1, 2, 3, 4, 5, 6, 7);
-          dqacc[j % BDB] = M::mfma(__builtin_bit_cast(vec8, k8), df[j / (2 * BDB)][(j / BDB) % 2], dqacc[j % BDB]);
+          dqacc[j % BDB] = M::mfma(__builtin_bit_cast(vec8, k8), df[j / BDB], dqacc[j % BDB]);
           if (j + LA2 < NJ) tread(j + LA2);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
     }  // sub-tiles
+#pragma unroll
+    for (int ks = 0; ks < BKS; ++ks) {
+      koff[ks] += flip;
+      asm volatile("" : "+v"(koff[ks]));
+    }
+#pragma unroll
+    for (int tv = 0; tv < NTV; ++tv)
+#pragma unroll
+      for (int db = 0; db < BDB; ++db) {
+        voff[tv][db] += flip;
+        asm volatile("" : "+v"(voff[tv][db]));
+      }
+    flip = -flip;
     if (t + 1 < nT) stage_write(buf ^ 1);
     __syncthreads();
   }
