@@ -80,7 +80,17 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define FA_BWD_OCC_DQ128 2  // head_dim-128 dQ kernel: 64 KiB of LDS and at most 256 registers -> two workgroups per CU
 #endif
 constexpr int bwd_sub_dq(int D) { return D == 64 ? FA_BWD_SUB_DQ64 : FA_BWD_SUB_DQ128; }
-constexpr int bwd_sub_kv(int D) { return D == 64 ? FA_BWD_SUB_KV64 : FA_BWD_SUB; }
+#ifndef FA_BWD_SUB_KV128
+#define FA_BWD_SUB_KV128 1
+#endif
+#ifndef FA_BWD_KV128_LA
+#define FA_BWD_KV128_LA 1  // read-ahead depths of the head_dim-128 dK/dV kernel (256 registers at two workgroups per CU)
+#define FA_BWD_KV128_LA2 1
+#endif
+#ifndef FA_BWD_OCC_KV128
+#define FA_BWD_OCC_KV128 2
+#endif
+constexpr int bwd_sub_kv(int D) { return D == 64 ? FA_BWD_SUB_KV64 : FA_BWD_SUB_KV128; }
 
 // per-head-dim constants of the kernels below (the reference kernel is head_dim 64 only, kernels.metal:905-1265;
 // 128 is the same algorithm with twice the k-steps / output blocks and one workgroup per CU)
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC_DQ : FA_BWD_OCC_DQ1
 // dK, dV: workgroup = 128 keys, wave = 32 keys (key on the lane, queries in the registers)
 // ---------------------------------------------------------------------------
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : 1)) void bwd_dkdv_kernel(BwdParams p) {
+__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : FA_BWD_OCC_KV128)) void bwd_dkdv_kernel(BwdParams p) {
   FA_BWD_CONSTS(D, bwd_sub_kv(D));
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
@@ -500,8 +510,8 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : 1)) void bwd_dkdv
       const bool need_mask = CAUSAL && (qt0 < kw0 + WM - 1);
       // One 32-query half (qb) at a time -- scores, P / dS, then its share of dV / dK -- so that only ONE score and ONE dP tuple
       // are live (round 3 first kept both halves': 212 VGPR, two waves per SIMD; this form fits three).
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      static_for<0, 2>([&](auto qbc) {
+        constexpr int qb = decltype(qbc)::value;
         f32x16 sq, dpq;
         __builtin_amdgcn_s_setprio(1);  // matrix phases above the other wave's arithmetic (as in the forward kernel)
         // the chains start from the row constants: registers 4g..4g+3 are query rows 32qb + 8g + 4h + 0..3 of the sub-tile
@@ -520,40 +530,42 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : 1)) void bwd_dkdv
           }
         }
         {
-          constexpr int NF = 2 * BKS, LA = FA_BWD_LA;
+          constexpr int NF = 2 * BKS, LA = BD == 128 ? FA_BWD_KV128_LA : FA_BWD_LA;
           vec8 fr[NF];
-          auto fread = [&](int f) {  // f = (ks, which): which 0 = Q row fragment, 1 = dO row fragment
-            fr[f] = __builtin_bit_cast(vec8, lds_read_b128(at(koff[f / 2] + ((f & 1) ? OS : QS) + qb * 32 * BRB)));
+          auto fread = [&](auto fc) {  // f = (ks, which): which 0 = Q row fragment, 1 = dO row fragment
+            constexpr int f = decltype(fc)::value;
+            fr[f] = __builtin_bit_cast(
+                vec8, lds_read_b128(at(koff[f / 2] + ((f & 1) ? OS : QS) + qb * 32 * BRB)));
           };
-#pragma unroll
-          for (int f = 0; f < LA; ++f) fread(f);
+          static_for<0, LA>([&](auto fc) { fread(fc); });
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int f = 0; f < NF; ++f) {
-            if (f & 1) dpq = M::mfma(fr[f], vf[f / 2], dpq);
+          static_for<0, NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f & 1) dpq = M::mfma(fr[f], vf[f / 2], dpq);
             else sq = M::mfma(fr[f], kf[f / 2], sq);
-            if (f + LA < NF) fread(f + LA);
+            if constexpr (f + LA < NF) fread(std::integral_constant<int, f + LA>{});
             __builtin_amdgcn_sched_barrier(0);
-          }
+          });
         }
         // dV / dK fragments of this half (step j = (st, db, which): which 0 = dO^T fragment -> dV, 1 = Q^T fragment -> dK) are
         // read LA2 steps ahead of their MFMA, the first ones before the P / dS arithmetic (they do not depend on it)
-        constexpr int NJ = 4 * BDB, LA2 = FA_BWD_LA2, TV = BD == 64 ? 4 : 2;
+        constexpr int NJ = 4 * BDB, LA2 = BD == 128 ? FA_BWD_KV128_LA2 : FA_BWD_LA2, TV = BD == 64 ? 4 : 2;
         s16x4 tlo[NJ], thi[NJ];
-        auto tread = [&](int j) {
-          const int jj = j / 2, R0 = 32 * qb + 16 * (jj / BDB), db = jj % BDB;
+        auto tread = [&](auto jc) {
+          constexpr int j = decltype(jc)::value, jj = j / 2, R0 = 32 * qb + 16 * (jj / BDB), db = jj % BDB;
           const int src = (j & 1) ? QS : OS;
           tlo[j] = lds_read_tr16(at(voff[(R0 >> 3) % TV][db] + src + R0 * BRB));
           thi[j] = lds_read_tr16(at(voff[((R0 >> 3) + 1) % TV][db] + src + (R0 + 8) * BRB));
         };
-#pragma unroll
-        for (int j = 0; j < LA2; ++j) tread(j);
+        static_for<0, LA2>([&](auto jc) { tread(jc); });
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
         if (need_mask) {  // key > query (kernels.metal:748): S' = -inf there. A wave-uniform BRANCH: written as a per-element
-#pragma unroll            // condition hipcc turned it into 32 compare + select pairs on every tile (seen in the ISA)
-          for (int i = 0; i < 16; ++i)
-            sq[i] = (qt0 + 32 * qb + 8 * (i >> 2) + 4 * h + (i & 3) < krow) ? -INFINITY : sq[i];
+          // condition hipcc turned it into 32 compare + select pairs on every tile (seen in the ISA). Register 4g+e holds query
+          // qt0 + 32qb + 8g + 4h + e: compared as a constant against ONE per-lane limit (else: sixteen threshold registers)
+          const int lim = krow - 4 * h - qt0 - 32 * qb;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sq[i] = (8 * (i >> 2) + (i & 3) < lim) ? -INFINITY : sq[i];
         }
         vec8 pf[2], df[2];
 #pragma unroll
@@ -571,16 +583,15 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : 1)) void bwd_dkdv
           }
         // dV^T += dO^T.P ; dK^T += Q^T.dS   (reduction over this half's 32 query rows)
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int jj = j / 2, st = jj / BDB, db = jj % BDB;
+        static_for<0, NJ>([&](auto jc) {
+          constexpr int j = decltype(jc)::value, jj = j / 2, st = jj / BDB, db = jj % BDB;
           const s16x8 a8 = __builtin_shufflevector(tlo[j], thi[j], 0, 1, 2, 3, 4, 5, 6, 7);
-          if (j & 1) dkacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), df[st], dkacc[db]);
+          if constexpr (j & 1) dkacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), df[st], dkacc[db]);
           else dvacc[db] = M::mfma(__builtin_bit_cast(vec8, a8), pf[st], dvacc[db]);
-          if (j + LA2 < NJ) tread(j + LA2);
+          if constexpr (j + LA2 < NJ) tread(std::integral_constant<int, j + LA2>{});
           __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+        });
+      });
     }
     }  // sub-tiles
 #pragma unroll

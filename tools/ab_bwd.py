@@ -6,7 +6,7 @@ import argparse, ctypes, os, time
 from ctypes import c_int, c_float, c_longlong, c_void_p
 import torch
 SHAPES = {"c3": (4, 16, 4096, 64, "bf16", 1), "nc4k": (4, 16, 4096, 64, "bf16", 0), "b16h8": (16, 8, 4096, 64, "bf16", 1),
-          "c8k": (4, 16, 8192, 64, "bf16", 1), "c1k": (4, 16, 1024, 64, "bf16", 1), "d128c4k": (1, 32, 4096, 128, "bf16", 1),
+          "c8k": (4, 16, 8192, 64, "bf16", 1), "c1k": (4, 16, 1024, 64, "bf16", 1), "d128c4k": (1, 32, 4096, 128, "bf16", 1), "d128nc4k": (1, 32, 4096, 128, "bf16", 0), "d128c8k": (2, 16, 8192, 128, "bf16", 1),
           "c3f16": (4, 16, 4096, 64, "f16", 1)}
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--shapes", default="c3,nc4k,b16h8")
 ap.add_argument("--rounds", type=int, default=6); ap.add_argument("--iters", type=int, default=6)
