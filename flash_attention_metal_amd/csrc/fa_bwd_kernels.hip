@@ -40,10 +40,12 @@ struct BwdParams {
   const float *lse;
   float *dq, *dk, *dv;
   float *delta;  // workspace [B,H,N]
-  int B, H, N, D;
+  int B, H, N, D;  // H = query heads
   float scale;
-  long long batch_stride, head_stride;
+  long long batch_stride, head_stride;  // of Q, O, dO, dQ (elements)
   int is_causal;
+  int Hkv;                                    // key/value heads: query head h reads (and dK/dV sum over) key head h / (H / Hkv)
+  long long kv_batch_stride, kv_head_stride;  // of K, V, dK, dV
 };
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -144,12 +146,13 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC_DQ : FA_BWD_OCC_DQ1
   int bh, qb;
   map_block_div<CAUSAL>(blockIdx.x, p.B * p.H, nQ, bh, qb);
   const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
+  const long long base_kv = (long long)(bh / p.H) * p.kv_batch_stride + (long long)((bh % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
   const int q0 = qb * BM, qw0 = q0 + wave * WM, qrow = qw0 + r;
 
   const unsigned head_bytes = (unsigned)p.N * BRB;
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.q + base), 0, head_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base), 0, head_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base_kv), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base_kv), 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.d_o + base), 0, head_bytes, 0x00020000);
 
   vec8 qf[BKS], dof[BKS];  // B operands: lane (r,h) holds row qrow, columns 16ks+8h..
@@ -380,17 +383,18 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : FA_BWD_OCC_KV128)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int BH = p.B * p.H;
-  const int kvb = blockIdx.x / BH;  // ascending: under the causal mask the first key blocks see the most queries
-  const int bh = blockIdx.x % BH;
-  const long long base = (long long)(bh / p.H) * p.batch_stride + (long long)(bh % p.H) * p.head_stride;
+  // one workgroup per (key block, key/value head): it visits the G = H / Hkv query heads that read this head one after the
+  // other, so grouped-query dK / dV are summed in registers (kernels.metal has one head count; G = 1 is its case)
+  const int BHK = p.B * p.Hkv, G = p.H / p.Hkv;
+  const int kvb = blockIdx.x / BHK;  // ascending: under the causal mask the first key blocks see the most queries
+  const int bhk = blockIdx.x % BHK, bi = bhk / p.Hkv, hk = bhk % p.Hkv;
+  const long long base = (long long)bi * p.kv_batch_stride + (long long)hk * p.kv_head_stride;  // K, V, dK, dV
   const int k0 = kvb * BM, kw0 = k0 + wave * WM, krow = kw0 + r;
 
   const unsigned head_bytes = (unsigned)p.N * BRB;
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.q + base), 0, head_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rq, rdo;  // of the query head being visited (set_head)
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base), 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base), 0, head_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.d_o + base), 0, head_bytes, 0x00020000);
 
   vec8 kf[BKS], vf[BKS];  // B operands: lane (r,h) holds key row krow, columns 16ks+8h..
 #pragma unroll
@@ -435,7 +439,14 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : FA_BWD_OCC_KV128)
   // iteration (seen in the ISA: the memory latency was exposed once per tile). It is scaled / negated in stage_write.
   float rowv = 0.0f;
   // (2 BT threads = whole waves: the choice of array is wave-uniform and stays in scalar registers)
-  const float *row_src = (__builtin_amdgcn_readfirstlane(tid) < BT ? p.lse : p.delta) + (long long)bh * p.N;
+  const float *row_src = nullptr;
+  auto set_head = [&](int g) {
+    const int hq = hk * G + g;
+    const long long bq = (long long)bi * p.batch_stride + (long long)hq * p.head_stride;
+    rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.q + bq), 0, head_bytes, 0x00020000);
+    rdo = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.d_o + bq), 0, head_bytes, 0x00020000);
+    row_src = (__builtin_amdgcn_readfirstlane(tid) < BT ? p.lse : p.delta) + (long long)(bi * p.H + hq) * p.N;
+  };
   constexpr bool DMA = FA_BWD_DMA != 0;
   const unsigned dvo = dma_off(wave, lane);
   auto stage_load = [&](int t, int buf) {
@@ -483,6 +494,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : FA_BWD_OCC_KV128)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dkacc[db][i] = 0.0f; dvacc[db][i] = 0.0f; }
 
+  set_head(0);
   if (t_begin < nTq) {
     stage_load(t_begin, 0);
     stage_write(0, t_begin);
@@ -495,8 +507,17 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : FA_BWD_OCC_KV128)
   for (int ks = 0; ks < BKS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
   __syncthreads();
 
+  int buf = 0;  // the buffer koff / voff / rowoff point into
+  for (int g = 0; g < G; ++g) {
+  if (g > 0) {  // next query head of the group (every wave is past the last tile's barrier: both buffers are free)
+    set_head(g);
+    if (t_begin < nTq) {
+      stage_load(t_begin, buf);
+      stage_write(buf, t_begin);
+    }
+    __syncthreads();
+  }
   for (int t = t_begin; t < nTq; ++t) {
-    const int buf = (t - t_begin) & 1;
     if (t + 1 < nTq) stage_load(t + 1, buf ^ 1);
 #pragma unroll
     for (int sub = 0; sub < BSUB; ++sub) {
@@ -612,7 +633,9 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : FA_BWD_OCC_KV128)
     flip_rows = -flip_rows;
     if (t + 1 < nTq) stage_write(buf ^ 1, t + 1);
     __syncthreads();
+    buf ^= 1;
   }
+  }  // query heads of the group
   if (krow < p.N) {
     float *dk = p.dk + base + (long long)krow * BD, *dv = p.dv + base + (long long)krow * BD;
 #pragma unroll
@@ -646,7 +669,7 @@ static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
   }
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
   hipLaunchKernelGGL(kq, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
-  hipLaunchKernelGGL(kk, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_kv, s, p);
+  hipLaunchKernelGGL(kk, dim3(nB * p.B * p.Hkv), dim3(NTHREADS), smem_kv, s, p);
   return hipGetLastError();
 }
 
@@ -657,13 +680,14 @@ static hipError_t launch_bwd_dt(const BwdParams &p, hipStream_t s) {
 }
 
 hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
-                      float *dq, float *dk, float *dv, float *ws, int B, int H, int N, int D, float scale,
-                      long long bs, long long hs, int causal, int dtype, hipStream_t s) {
+                      float *dq, float *dk, float *dv, float *ws, int B, int H, int Hkv, int N, int D, float scale,
+                      long long bs, long long hs, long long kv_bs, long long kv_hs, int causal, int dtype, hipStream_t s) {
   BwdParams p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse = lse;
   p.dq = dq; p.dk = dk; p.dv = dv; p.delta = ws;
   p.B = B; p.H = H; p.N = N; p.D = D; p.scale = scale;
   p.batch_stride = bs; p.head_stride = hs; p.is_causal = causal;
+  p.Hkv = Hkv; p.kv_batch_stride = kv_bs; p.kv_head_stride = kv_hs;
   return dtype == FA_DTYPE_F16 ? launch_bwd_dt<F16>(p, s) : launch_bwd_dt<BF16>(p, s);
 }
 

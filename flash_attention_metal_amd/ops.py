@@ -192,31 +192,37 @@ def flash_attention_backward(
     scale: Optional[float] = None,
     stream: Optional[int] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """(Q,K,V,O,dO,LSE) -> (dQ,dK,dV) in fp32, same [B,H,N,D] layout (binding table of
-    /root/reference/kernels.metal:905-921; gradients are written, not accumulated)."""
+    """(Q,K,V,O,dO,LSE) -> (dQ,dK,dV) in fp32, laid out like their inputs (binding table of
+    /root/reference/kernels.metal:905-921; gradients are written, not accumulated). k / v may carry fewer heads than q
+    (grouped-query attention, include/fa_mi355.h fa_bwd_ex): dK / dV then have k's shape."""
     lib = load_library()
-    if q.dim() != 4 or any(t.shape != q.shape for t in (k, v, o, d_o)):
-        raise ValueError("q, k, v, o, d_o must share one [B,H,N,D] shape")
+    if q.dim() != 4 or any(t.shape != q.shape for t in (o, d_o)) or k.dim() != 4 or v.shape != k.shape:
+        raise ValueError("q, o, d_o must share one [B,Hq,N,D] shape and k, v one [B,Hkv,N,D] shape")
     if not all(t.is_cuda for t in (q, k, v, o, d_o, lse)):
         raise RuntimeError("flash_attention_backward needs device tensors: there is no CPU path")
     if q.dtype not in (torch.float16, torch.bfloat16) or any(t.dtype != q.dtype for t in (k, v, o, d_o)):
         raise ValueError("backward supports f16 / bf16 tensors of one dtype")
     B, H, N, D = q.shape
+    Bk, Hkv, Nk, Dk = k.shape
+    if (Bk, Nk, Dk) != (B, N, D) or H % Hkv:
+        raise ValueError(f"k/v shape {tuple(k.shape)} does not fit q {tuple(q.shape)} (same B, N, D; Hq % Hkv == 0)")
     bs, hs = _strides(q)
-    if any(_strides(t) != (bs, hs) for t in (k, v, o, d_o)):
-        raise ValueError("all tensors must share batch/head strides")
+    kbs, khs = _strides(k)
+    if any(_strides(t) != (bs, hs) for t in (o, d_o)) or _strides(v) != (kbs, khs):
+        raise ValueError("q, o, d_o must share batch/head strides, and so must k, v")
     if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != B * H * N:
         raise ValueError("lse must be contiguous fp32 [B,H,N]")
-    dq, dk, dv = (torch.empty_strided((B, H, N, D), q.stride(), dtype=torch.float32, device=q.device) for _ in range(3))
+    dq = torch.empty_strided((B, H, N, D), q.stride(), dtype=torch.float32, device=q.device)
+    dk, dv = (torch.empty_strided((B, Hkv, N, D), k.stride(), dtype=torch.float32, device=q.device) for _ in range(2))
     ws = torch.empty(lib.fa_bwd_workspace_bytes(B, H, N), dtype=torch.uint8, device=q.device)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     if stream is None:
         stream = torch.cuda.current_stream(q.device).cuda_stream
     with torch.cuda.device(q.device):
-        st = lib.fa_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
-                        dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, H, N, D, float(scale), bs, hs,
-                        int(bool(is_causal)), _TORCH2FA[q.dtype], stream)
+        st = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
+                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, H, Hkv, N, D, float(scale), bs, hs,
+                           kbs, khs, int(bool(is_causal)), _TORCH2FA[q.dtype], stream)
     if st != 0:
         raise FaError(st, lib.fa_last_error().decode())
     return dq, dk, dv

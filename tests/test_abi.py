@@ -37,7 +37,7 @@ def test_header_symbols_all_exported(fa):
 
 def test_version_and_names(fa):
     lib = fa.load_library()
-    assert lib.fa_version() == 300
+    assert lib.fa_version() == 301
     assert [lib.fa_variant_name(i).decode() for i in range(10)] == ["auto", "naive", "tiled", "tiled_v2", "mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2"]
     assert [lib.fa_dtype_name(i).decode() for i in range(4)] == ["f32", "f16", "bf16", "fp8_e4m3"]
 
@@ -107,6 +107,11 @@ def test_ex_and_bwd_reject_bad_strides_and_oversized_grids(fa):
     assert lib.fa_bwd(ok, ok, ok, ok, ok, f, f, f, f, f, 65536, 65536, 128, 64, 0.125, 65536 * 8192, 8192, 0, 2, None) == -1 \
         and b"grid" in lib.fa_last_error()
     assert lib.fa_bwd(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 2, 128, 64, 0.125, -16384, 8192, 0, 2, None) == -1
+    # grouped-query backward: Hkv must divide Hq; the key/value strides are checked like the query's
+    assert lib.fa_bwd_ex(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 6, 4, 128, 64, 0.125, 6 * 8192, 8192, 4 * 8192, 8192, 0, 2, None) == -1 \
+        and b"Hkv" in lib.fa_last_error()
+    assert lib.fa_bwd_ex(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 4, 2, 128, 64, 0.125, 4 * 8192, 8192, 2 * 8192, 100, 0, 2, None) == -1 \
+        and b"key/value strides" in lib.fa_last_error()
     assert big > 0
 
 

@@ -57,6 +57,48 @@ def test_backward_vs_oracle(fa, oracle_mod, dtype, causal, D):
             assert rel(g, ref) < TOL[dtype], (name, dtype, causal, B, H, N, rel(g, ref))
 
 
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_grouped_query_heads(fa, oracle_mod, causal, D):
+    """fa_bwd_ex (scope rows f1 + f3): query head h reads key/value head h // G; dK / dV of a key head are the sums over its
+    G query heads. Oracle: the fp64 backward on K / V repeated to Hq heads, its dK / dV summed per group."""
+    import torch
+
+    dtype = "bf16"
+    for (B, Hq, Hkv, N) in ((1, 4, 2, 200), (2, 6, 1, 129), (1, 8, 4, 64), (1, 3, 3, 130)):
+        G = Hq // Hkv
+        q, _, _ = make_qkv(oracle_mod, B, Hq, N, D, dtype)
+        _, k, v = make_qkv(oracle_mod, B, Hkv, N, D, dtype)
+        do = oracle_mod.round_to(oracle_mod.init_random(B * Hq * N * D, 45).reshape(B, Hq, N, D), dtype)
+        qd, kd, vd, dod = (to_dev(x, dtype) for x in (q, k, v, do))
+        o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal)
+        dq, dk, dv = fa.flash_attention_backward(qd, kd, vd, o, dod, lse, is_causal=causal)
+        torch.cuda.synchronize()
+        assert dq.shape == qd.shape and dk.shape == kd.shape and dv.shape == kd.shape
+        ke, ve = (np.ascontiguousarray(np.repeat(x, G, axis=1)) for x in (k, v))
+        rq, rk, rv = oracle_mod.attn_bwd_f64(q, ke, ve, do, causal)
+        rk, rv = (x.reshape(B, Hkv, G, N, D).sum(2) for x in (rk, rv))
+        for name, g, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+            g = g.cpu().numpy()
+            assert np.isfinite(g).all(), (name, B, Hq, Hkv, N)
+            assert rel(g, ref) < TOL[dtype], (name, causal, B, Hq, Hkv, N, rel(g, ref))
+    # through torch.autograd (row f4): grouped heads against torch's own attention on the repeated K / V
+    from flash_attention_metal_amd.torch_op import attention_forward
+
+    q, _, _ = make_qkv(oracle_mod, 1, 4, 160, D, dtype)
+    _, k, v = make_qkv(oracle_mod, 1, 2, 160, D, dtype)
+    qd, kd, vd = (to_dev(x, dtype).requires_grad_(True) for x in (q, k, v))
+    o, _ = attention_forward(qd, kd, vd, causal)
+    w = torch.linspace(-1, 1, o.numel(), device="cuda").reshape(o.shape)
+    (o.float() * w).sum().backward()
+    q2, k2, v2 = (to_dev(x, dtype).double().requires_grad_(True) for x in (q, k, v))
+    o2 = torch.nn.functional.scaled_dot_product_attention(q2, k2.repeat_interleave(2, 1), v2.repeat_interleave(2, 1), is_causal=causal)
+    (o2 * w.to(dtype=getattr(torch, {"bf16": "bfloat16", "f16": "float16"}[dtype])).double()).sum().backward()
+    for a, b_ in ((qd.grad, q2.grad), (kd.grad, k2.grad), (vd.grad, v2.grad)):
+        assert a.shape == b_.shape
+        assert (a.double() - b_).abs().max().item() / b_.abs().max().item() < 3e-2
+
+
 def test_backward_known_answers(fa, oracle_mod):
     import torch
 
