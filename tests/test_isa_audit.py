@@ -85,3 +85,44 @@ def test_compiled_kernels_keep_hazard_distance_own_their_registers_and_use_no_sc
                 assert scratch == 0, (name, scratch)
                 assert sum("buffer_load_dwordx4" in t and " lds" in t for _, t in lines) > 0, name
         assert not bad, bad[:5]
+
+
+def makefile_flags(stem):
+    """CXXFLAGS + FLAGS_<stem> exactly as csrc/Makefile passes them (an audit of other flags audits another kernel: round 3
+    measured registers with -fno-slp-vectorize while the Makefile built the backward without it)."""
+    import re
+
+    text = open(os.path.join(ROOT, "flash_attention_metal_amd", "csrc", "Makefile")).read()
+    cxx = re.search(r"^CXXFLAGS\s*:=\s*(.*)$", text, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    own = re.search(rf"^FLAGS_{stem}\s*:=\s*(.*)$", text, re.M)
+    return cxx + (own.group(1).split() if own else [])
+
+
+def test_backward_kernels_fit_their_occupancy_without_scratch():
+    # The backward kernels are compiled for three (head_dim 64) / two (head_dim 128) workgroups per CU: 168 / 256 registers.
+    # What must hold is that the hot loops do not spill: head_dim 64 not at all, head_dim 128 at most the 32 bytes the dK/dV
+    # kernel keeps OUTSIDE its tile loop (per-head constants, reloaded once per query head of the group; seen in the ISA).
+    import re
+
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    flags = makefile_flags("fa_bwd_kernels")
+    assert "-fno-slp-vectorize" in flags  # packed fp32 + shuffles in front of the bf16 packing: 10 % slower (profiles/r03)
+    src = os.path.join(ROOT, "flash_attention_metal_amd", "csrc", "fa_bwd_kernels.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([hipcc] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"], cwd=tmp,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+    rows = re.findall(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
+                      r.stderr, re.S)
+    seen = {}
+    for name, vg, ag, scratch, occ in rows:
+        if "bwd_" in name:
+            seen[name] = (int(vg), int(ag), int(scratch), int(occ))
+    assert len(seen) == 16, sorted(seen)  # {dq, dkdv} x {f16, bf16} x {64, 128} x {causal, full}
+    for name, (vg, ag, scratch, occ) in seen.items():
+        if "Li64E" in name:
+            assert vg + ag <= 168 and scratch == 0 and occ == 3, (name, vg, ag, scratch, occ)
+        else:
+            assert vg + ag <= 256 and scratch <= 32 and occ == 2, (name, vg, ag, scratch, occ)
