@@ -31,6 +31,11 @@
 // chunk swizzle that keeps both kinds of read (and the staging stores) free of bank conflicts (cdna guide T10, "one image
 // for row reads and transposed reads"; round 2 kept two images and paid the LDS store bandwidth twice -- these kernels
 // are LDS-bound: every MFMA takes a 1 KiB fragment from LDS, half the LDS bandwidth at full matrix rate, before any store).
+// Second half of round 3: each 64-row sub-tile is worked one 32-row half at a time (scores, P / dS, then that half's share
+// of the second products), so one score and one dP tuple are live; the per-lane LDS addresses are ABSOLUTE addresses in the
+// current buffer, moved to the other buffer in place once per tile. Together: 160-166 registers, three workgroups per CU at
+// head_dim 64 (config-3 shape 692 -> 811 TFLOP/s with the SLP vectorizer off, profiles/r03/ab_bwd_*.log).
+// Grouped-query heads (fa_bwd_ex): the dK/dV workgroup of a key/value head visits its H / Hkv query heads in turn.
 #include "fa_mfma_common.h"
 
 namespace fa {
@@ -54,48 +59,29 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define FA_BWD_DMA 1  // 1: the streamed tiles go global -> LDS by LDS-DMA (buffer_load ... lds; the chunk swizzle sits on the source address):
 #endif                // no staging registers, no ds_write_b128 (as in the forward kernels, profiles/r03/ab_mfma_lds_dma.log); 0 = register staging
 #ifndef FA_BWD_LA
-#define FA_BWD_LA 3  // dK/dV kernel: row fragments are read this many MFMAs ahead of their use
+#define FA_BWD_LA 3  // row fragments are read this many MFMAs ahead of their use
 #endif
 #ifndef FA_BWD_LA2
-#define FA_BWD_LA2 2  // dK/dV kernel: the same for the transposed fragments
-#endif
-#ifndef FA_BWD_OCC_DQ
-#define FA_BWD_OCC_DQ 3  // the same for the dQ kernel
-#endif
-#ifndef FA_BWD_OCC
-#define FA_BWD_OCC 3  // workgroups per CU the head_dim-64 dK/dV kernel is compiled for (register cap 168)
-#endif
-// 64-row sub-tiles per staged tile: one barrier and one staging pass per SUB * 64 keys (dQ) / queries (dK, dV)
-#ifndef FA_BWD_SUB
-#define FA_BWD_SUB 2
-#endif
-#ifndef FA_BWD_SUB_KV64
-#define FA_BWD_SUB_KV64 1  // head_dim-64 dK/dV kernel: 34 KiB of LDS per workgroup, three workgroups per CU
-#endif
-#ifndef FA_BWD_SUB_DQ64
-#define FA_BWD_SUB_DQ64 1
-#endif
-#ifndef FA_BWD_SUB_DQ128
-#define FA_BWD_SUB_DQ128 1
-#endif
-#ifndef FA_BWD_OCC_DQ128
-#define FA_BWD_OCC_DQ128 2  // head_dim-128 dQ kernel: 64 KiB of LDS and at most 256 registers -> two workgroups per CU
-#endif
-constexpr int bwd_sub_dq(int D) { return D == 64 ? FA_BWD_SUB_DQ64 : FA_BWD_SUB_DQ128; }
-#ifndef FA_BWD_SUB_KV128
-#define FA_BWD_SUB_KV128 1
+#define FA_BWD_LA2 2  // the same for the transposed fragments
 #endif
 #ifndef FA_BWD_KV128_LA
-#define FA_BWD_KV128_LA 1  // read-ahead depths of the head_dim-128 dK/dV kernel (256 registers at two workgroups per CU)
+#define FA_BWD_KV128_LA 1  // the head_dim-128 dK/dV kernel (256 registers at two workgroups per CU) affords one step of each
 #define FA_BWD_KV128_LA2 1
 #endif
-#ifndef FA_BWD_OCC_KV128
-#define FA_BWD_OCC_KV128 2
+// Workgroups per CU the kernels are compiled for: three at head_dim 64 (register cap 168, 32-34 KiB of LDS), two at 128
+// (cap 256, 64-66 KiB). Round 3 first ran two / one (205-214 registers): see bwd_dq_kernel for what brought them down.
+constexpr int bwd_occ(int D) { return D == 64 ? 3 : 2; }
+// 64-row sub-tiles per staged tile: one barrier and one staging pass per SUB * 64 keys (dQ) / queries (dK, dV). 2 paid while
+// one workgroup per CU exposed every barrier (+16 % at head_dim 128 then); at the occupancy above 1 is faster and is what
+// fits the LDS (profiles/r03/ab_bwd_dq_per_half.log).
+#ifndef FA_BWD_SUB
+#define FA_BWD_SUB 1
 #endif
-constexpr int bwd_sub_kv(int D) { return D == 64 ? FA_BWD_SUB_KV64 : FA_BWD_SUB_KV128; }
+constexpr int bwd_sub_dq(int D) { return FA_BWD_SUB; }
+constexpr int bwd_sub_kv(int D) { return FA_BWD_SUB; }
 
 // per-head-dim constants of the kernels below (the reference kernel is head_dim 64 only, kernels.metal:905-1265;
-// 128 is the same algorithm with twice the k-steps / output blocks and one workgroup per CU)
+// 128 is the same algorithm with twice the k-steps / output blocks and two workgroups per CU)
 #define FA_BWD_CONSTS(D, SUBS)                                                                   \
   constexpr int BSUB = (SUBS);     /* sub-tiles per staged tile */                               \
   constexpr int BT = BSUB * BN;    /* rows of a staged tile */                                   \
@@ -129,7 +115,7 @@ constexpr int bwd_sub_kv(int D) { return D == 64 ? FA_BWD_SUB_KV64 : FA_BWD_SUB_
 // dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
 // ---------------------------------------------------------------------------
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC_DQ : FA_BWD_OCC_DQ128)) void bwd_dq_kernel(BwdParams p) {
+__global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams p) {
   FA_BWD_CONSTS(D, bwd_sub_dq(D));
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
@@ -369,7 +355,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC_DQ : FA_BWD_OCC_DQ1
 // dK, dV: workgroup = 128 keys, wave = 32 keys (key on the lane, queries in the registers)
 // ---------------------------------------------------------------------------
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA_BWD_OCC : FA_BWD_OCC_KV128)) void bwd_dkdv_kernel(BwdParams p) {
+__global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParams p) {
   FA_BWD_CONSTS(D, bwd_sub_kv(D));
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
