@@ -237,26 +237,29 @@ double fa_bwd_algorithmic_flops(int B, int H, int N, int D, int is_causal) {
 }
 
 static int bwd_impl(const char *fn, const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
-                    float *dq, float *dk, float *dv, void *workspace, int B, int H, int Hkv, int N, int D, float scale,
+                    float *dq, float *dk, float *dv, void *workspace, int B, int H, int Hkv, int N, int Nk, int D, float scale,
                     long long bs, long long hs, long long kbs, long long khs, int is_causal, int dtype, void *hip_stream) {
   g_err[0] = 0;
   if (!q || !k || !v || !o || !d_o || !lse || !dq || !dk || !dv || !workspace)
     return fail(FA_ERR_INVALID_ARG, "%s: null pointer", fn);
-  if (B < 1 || H < 1 || N < 1 || D < 1) return fail(FA_ERR_INVALID_ARG, "%s: B=%d H=%d N=%d D=%d must be >= 1", fn, B, H, N, D);
+  if (B < 1 || H < 1 || N < 1 || Nk < 1 || D < 1)
+    return fail(FA_ERR_INVALID_ARG, "%s: B=%d H=%d Nq=%d Nk=%d D=%d must be >= 1", fn, B, H, N, Nk, D);
+  if (is_causal && Nk < N)
+    return fail(FA_ERR_UNSUPPORTED, "%s: causal needs Nk >= Nq (bottom-right alignment would leave empty rows)", fn);
   if (Hkv < 1 || H % Hkv) return fail(FA_ERR_INVALID_ARG, "%s: Hkv=%d must divide Hq=%d", fn, Hkv, H);
   if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "%s: scale=%g must be > 0", fn, (double)scale);
   if (hs < (long long)N * D || (H > 1 && bs < hs) || (bs % 8) || (hs % 8))
     return fail(FA_ERR_INVALID_ARG, "%s: bad strides (batch %lld, head %lld)", fn, bs, hs);
-  if (khs < (long long)N * D || (Hkv > 1 && kbs < khs) || (kbs % 8) || (khs % 8))
+  if (khs < (long long)Nk * D || (Hkv > 1 && kbs < khs) || (kbs % 8) || (khs % 8))
     return fail(FA_ERR_INVALID_ARG, "%s: bad key/value strides (batch %lld, head %lld)", fn, kbs, khs);
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)
     return fail(FA_ERR_INVALID_ARG, "%s: tensors must be 16-byte aligned", fn);
   if (!fa::bwd_supported(dtype, D))
     return fail(FA_ERR_UNSUPPORTED, "%s: no kernel for dtype=%s D=%d (f16/bf16, D=64|128)", fn, fa_dtype_name(dtype), D);
-  if ((double)N * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "%s: one head exceeds 4 GiB", fn);
+  if ((double)(N > Nk ? N : Nk) * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "%s: one head exceeds 4 GiB", fn);
   if (bs < 0 || kbs < 0) return fail(FA_ERR_INVALID_ARG, "%s: negative batch stride", fn);
-  if ((long long)B * H > 0x7fffffffLL / ((N + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "%s: grid too large", fn);
-  hipError_t e = fa::launch_bwd(q, k, v, o, d_o, lse, dq, dk, dv, (float *)workspace, B, H, Hkv, N, D, scale, bs, hs, kbs, khs,
+  if ((long long)B * H > 0x7fffffffLL / (((N > Nk ? N : Nk) + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "%s: grid too large", fn);
+  hipError_t e = fa::launch_bwd(q, k, v, o, d_o, lse, dq, dk, dv, (float *)workspace, B, H, Hkv, N, Nk, D, scale, bs, hs, kbs, khs,
                                 is_causal ? 1 : 0, dtype, (hipStream_t)hip_stream);
   if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: launch failed: %s", fn, hipGetErrorString(e));
   return FA_OK;
@@ -265,15 +268,15 @@ static int bwd_impl(const char *fn, const void *q, const void *k, const void *v,
 int fa_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse, float *dq,
            float *dk, float *dv, void *workspace, int B, int H, int N, int D, float scale, long long batch_stride,
            long long head_stride, int is_causal, int dtype, void *hip_stream) {
-  return bwd_impl("fa_bwd", q, k, v, o, d_o, lse, dq, dk, dv, workspace, B, H, H, N, D, scale, batch_stride, head_stride,
+  return bwd_impl("fa_bwd", q, k, v, o, d_o, lse, dq, dk, dv, workspace, B, H, H, N, N, D, scale, batch_stride, head_stride,
                   batch_stride, head_stride, is_causal, dtype, hip_stream);
 }
 
 int fa_bwd_ex(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse, float *dq,
-              float *dk, float *dv, void *workspace, int B, int Hq, int Hkv, int N, int D, float scale,
+              float *dk, float *dv, void *workspace, int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
               long long q_batch_stride, long long q_head_stride, long long kv_batch_stride, long long kv_head_stride,
               int is_causal, int dtype, void *hip_stream) {
-  return bwd_impl("fa_bwd_ex", q, k, v, o, d_o, lse, dq, dk, dv, workspace, B, Hq, Hkv, N, D, scale, q_batch_stride,
+  return bwd_impl("fa_bwd_ex", q, k, v, o, d_o, lse, dq, dk, dv, workspace, B, Hq, Hkv, Nq, Nk, D, scale, q_batch_stride,
                   q_head_stride, kv_batch_stride, kv_head_stride, is_causal, dtype, hip_stream);
 }
 

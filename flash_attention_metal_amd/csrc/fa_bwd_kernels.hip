@@ -45,7 +45,8 @@ struct BwdParams {
   const float *lse;
   float *dq, *dk, *dv;
   float *delta;  // workspace [B,H,N]
-  int B, H, N, D;  // H = query heads
+  int B, H, N, D;  // H = query heads, N = query rows per head
+  int Nk;          // keys per head (causal: bottom-right aligned, key j visible to query i iff j <= i + Nk - N; Nk >= N then)
   float scale;
   long long batch_stride, head_stride;  // of Q, O, dO, dQ (elements)
   int is_causal;
@@ -135,10 +136,11 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
   const long long base_kv = (long long)(bh / p.H) * p.kv_batch_stride + (long long)((bh % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
   const int q0 = qb * BM, qw0 = q0 + wave * WM, qrow = qw0 + r;
 
-  const unsigned head_bytes = (unsigned)p.N * BRB;
+  const unsigned head_bytes = (unsigned)p.N * BRB, kv_head_bytes = (unsigned)p.Nk * BRB;
+  const int coff = p.Nk - p.N;
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.q + base), 0, head_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base_kv), 0, head_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base_kv), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base_kv), 0, kv_head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base_kv), 0, kv_head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.d_o + base), 0, head_bytes, 0x00020000);
 
   vec8 qf[BKS], dof[BKS];  // B operands: lane (r,h) holds row qrow, columns 16ks+8h..
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
     st_g[i] = row * BRB + ch * 16;
     st_r[i] = row * BRB + ((ch ^ u_swz(row)) << 4);
   }
-  const int kv_end = CAUSAL ? min(p.N, q0 + BM) : p.N;
+  const int kv_end = CAUSAL ? min(p.Nk, q0 + BM + coff) : p.Nk;
   const int nT = (kv_end + BT - 1) / BT;
 
   constexpr bool DMA = FA_BWD_DMA != 0;
@@ -257,9 +259,9 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
 #pragma unroll
     for (int sub = 0; sub < BSUB; ++sub) {
     const int kv0 = t * BT + sub * BN;
-    if (kv0 < kv_end && (!CAUSAL || kv0 <= qw0 + WM - 1)) {
+    if (kv0 < kv_end && (!CAUSAL || kv0 <= qw0 + WM - 1 + coff)) {
       const int KS = sub * BTILE, VS = 2 * STILE + sub * BTILE;  // K / V sub-tile images, relative to koff / voff
-      const bool need_mask = CAUSAL && (kv0 + BN - 1 > qw0);
+      const bool need_mask = CAUSAL && (kv0 + BN - 1 > qw0 + coff);
       // One 32-key half (kb) at a time -- scores, dS, then its share of dQ -- so that only one score and one dP tuple are live
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
         if (need_mask) {  // key > query -> masked (kernels.metal:748); a wave-uniform branch
-          const int lim = qrow - kv0 - 32 * kb - 4 * h;
+          const int lim = qrow + coff - kv0 - 32 * kb - 4 * h;
 #pragma unroll
           for (int i = 0; i < 16; ++i) sk[i] = ((i & 3) + 8 * (i >> 2) > lim) ? -INFINITY : sk[i];
         }
@@ -377,10 +379,11 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
   const long long base = (long long)bi * p.kv_batch_stride + (long long)hk * p.kv_head_stride;  // K, V, dK, dV
   const int k0 = kvb * BM, kw0 = k0 + wave * WM, krow = kw0 + r;
 
-  const unsigned head_bytes = (unsigned)p.N * BRB;
+  const unsigned head_bytes = (unsigned)p.N * BRB, kv_head_bytes = (unsigned)p.Nk * BRB;
+  const int coff = p.Nk - p.N;
   __amdgpu_buffer_rsrc_t rq, rdo;  // of the query head being visited (set_head)
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base), 0, head_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base), 0, kv_head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.v + base), 0, kv_head_bytes, 0x00020000);
 
   vec8 kf[BKS], vf[BKS];  // B operands: lane (r,h) holds key row krow, columns 16ks+8h..
 #pragma unroll
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
   }
   // query tiles of BT rows; under the causal mask only tiles that reach this block's first key
   const int nTq = (p.N + BT - 1) / BT;
-  const int t_begin = CAUSAL ? k0 / BT : 0;
+  const int t_begin = CAUSAL ? max(k0 - coff, 0) / BT : 0;  // the first query that sees key k0 is k0 - coff
   static_assert(2 * BT <= NTHREADS, "one thread per staged row constant");
 
   u32x4 qst[NCH], ost[NCH];
@@ -509,12 +512,12 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
     for (int sub = 0; sub < BSUB; ++sub) {
     const int sub_c = sub;
     const int qt0 = t * BT + sub * BN;
-    if (qt0 < p.N && (!CAUSAL || qt0 + BN - 1 >= kw0)) {  // some query of the sub-tile sees this wave's first key
+    if (qt0 < p.N && (!CAUSAL || qt0 + BN - 1 + coff >= kw0)) {  // some query of the sub-tile sees this wave's first key
       // (the buffer's offset is inside koff / voff / rowoff, toggled once per tile: everything added here is an immediate)
       const int QS = sub_c * BTILE, OS = 2 * STILE + sub_c * BTILE;  // Q / dO sub-tile images, relative to koff / voff
       const unsigned rows = rowoff + sub_c * (BN * 4);
       // only sub-tiles that cross the diagonal for this wave need the per-element mask (wave-uniform)
-      const bool need_mask = CAUSAL && (qt0 < kw0 + WM - 1);
+      const bool need_mask = CAUSAL && (qt0 + coff < kw0 + WM - 1);
       // One 32-query half (qb) at a time -- scores, P / dS, then its share of dV / dK -- so that only ONE score and ONE dP tuple
       // are live (round 3 first kept both halves': 212 VGPR, two waves per SIMD; this form fits three).
       static_for<0, 2>([&](auto qbc) {
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
         if (need_mask) {  // key > query (kernels.metal:748): S' = -inf there. A wave-uniform BRANCH: written as a per-element
           // condition hipcc turned it into 32 compare + select pairs on every tile (seen in the ISA). Register 4g+e holds query
           // qt0 + 32qb + 8g + 4h + e: compared as a constant against ONE per-lane limit (else: sixteen threshold registers)
-          const int lim = krow - 4 * h - qt0 - 32 * qb;
+          const int lim = krow - coff - 4 * h - qt0 - 32 * qb;
 #pragma unroll
           for (int i = 0; i < 16; ++i) sq[i] = (8 * (i >> 2) + (i & 3) < lim) ? -INFINITY : sq[i];
         }
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
     buf ^= 1;
   }
   }  // query heads of the group
-  if (krow < p.N) {
+  if (krow < p.Nk) {
     float *dk = p.dk + base + (long long)krow * BD, *dv = p.dv + base + (long long)krow * BD;
 #pragma unroll
     for (int db = 0; db < BDB; ++db)
@@ -642,7 +645,7 @@ bool bwd_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype ==
 template <typename Tag, int D, bool CAUSAL>
 static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
   constexpr int BTILE = BN * D * 2;
-  const int nB = (p.N + BM - 1) / BM;
+  const int nBq = (p.N + BM - 1) / BM, nBk = (p.Nk + BM - 1) / BM;
   const size_t smem_dq = 4 * bwd_sub_dq(D) * BTILE, smem_kv = 4 * bwd_sub_kv(D) * BTILE + 2 * 2 * bwd_sub_kv(D) * BN * 4;
   auto kq = bwd_dq_kernel<Tag, D, CAUSAL>;
   auto kk = bwd_dkdv_kernel<Tag, D, CAUSAL>;
@@ -654,8 +657,8 @@ static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
     if (e != hipSuccess) return e;
   }
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
-  hipLaunchKernelGGL(kq, dim3(nB * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
-  hipLaunchKernelGGL(kk, dim3(nB * p.B * p.Hkv), dim3(NTHREADS), smem_kv, s, p);
+  hipLaunchKernelGGL(kq, dim3(nBq * p.B * p.H), dim3(NTHREADS), smem_dq, s, p);
+  hipLaunchKernelGGL(kk, dim3(nBk * p.B * p.Hkv), dim3(NTHREADS), smem_kv, s, p);
   return hipGetLastError();
 }
 
@@ -666,14 +669,14 @@ static hipError_t launch_bwd_dt(const BwdParams &p, hipStream_t s) {
 }
 
 hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
-                      float *dq, float *dk, float *dv, float *ws, int B, int H, int Hkv, int N, int D, float scale,
+                      float *dq, float *dk, float *dv, float *ws, int B, int H, int Hkv, int N, int Nk, int D, float scale,
                       long long bs, long long hs, long long kv_bs, long long kv_hs, int causal, int dtype, hipStream_t s) {
   BwdParams p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.lse = lse;
   p.dq = dq; p.dk = dk; p.dv = dv; p.delta = ws;
   p.B = B; p.H = H; p.N = N; p.D = D; p.scale = scale;
   p.batch_stride = bs; p.head_stride = hs; p.is_causal = causal;
-  p.Hkv = Hkv; p.kv_batch_stride = kv_bs; p.kv_head_stride = kv_hs;
+  p.Hkv = Hkv; p.Nk = Nk; p.kv_batch_stride = kv_bs; p.kv_head_stride = kv_hs;
   return dtype == FA_DTYPE_F16 ? launch_bwd_dt<F16>(p, s) : launch_bwd_dt<BF16>(p, s);
 }
 

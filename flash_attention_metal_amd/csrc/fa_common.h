@@ -69,7 +69,7 @@ bool splitkv_supported(int dtype, int D);
 int splitkv_waves(int D, int Nk);
 bool bwd_supported(int dtype, int D);
 hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
-                      float *dq, float *dk, float *dv, float *ws, int B, int H, int Hkv, int N, int D, float scale,
+                      float *dq, float *dk, float *dv, float *ws, int B, int H, int Hkv, int N, int Nk, int D, float scale,
                       long long bs, long long hs, long long kv_bs, long long kv_hs, int causal, int dtype, hipStream_t s);
 
 // ---- element load/store helpers for the scalar kernels -------------------

@@ -193,8 +193,8 @@ def flash_attention_backward(
     stream: Optional[int] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """(Q,K,V,O,dO,LSE) -> (dQ,dK,dV) in fp32, laid out like their inputs (binding table of
-    /root/reference/kernels.metal:905-921; gradients are written, not accumulated). k / v may carry fewer heads than q
-    (grouped-query attention, include/fa_mi355.h fa_bwd_ex): dK / dV then have k's shape."""
+    /root/reference/kernels.metal:905-921; gradients are written, not accumulated). k / v may carry fewer heads than q and
+    another sequence length (include/fa_mi355.h fa_bwd_ex, the counterpart of fa_fwd_ex): dK / dV have k's shape."""
     lib = load_library()
     if q.dim() != 4 or any(t.shape != q.shape for t in (o, d_o)) or k.dim() != 4 or v.shape != k.shape:
         raise ValueError("q, o, d_o must share one [B,Hq,N,D] shape and k, v one [B,Hkv,N,D] shape")
@@ -204,8 +204,8 @@ def flash_attention_backward(
         raise ValueError("backward supports f16 / bf16 tensors of one dtype")
     B, H, N, D = q.shape
     Bk, Hkv, Nk, Dk = k.shape
-    if (Bk, Nk, Dk) != (B, N, D) or H % Hkv:
-        raise ValueError(f"k/v shape {tuple(k.shape)} does not fit q {tuple(q.shape)} (same B, N, D; Hq % Hkv == 0)")
+    if (Bk, Dk) != (B, D) or H % Hkv:
+        raise ValueError(f"k/v shape {tuple(k.shape)} does not fit q {tuple(q.shape)} (same B, D; Hq % Hkv == 0)")
     bs, hs = _strides(q)
     kbs, khs = _strides(k)
     if any(_strides(t) != (bs, hs) for t in (o, d_o)) or _strides(v) != (kbs, khs):
@@ -213,7 +213,7 @@ def flash_attention_backward(
     if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != B * H * N:
         raise ValueError("lse must be contiguous fp32 [B,H,N]")
     dq = torch.empty_strided((B, H, N, D), q.stride(), dtype=torch.float32, device=q.device)
-    dk, dv = (torch.empty_strided((B, Hkv, N, D), k.stride(), dtype=torch.float32, device=q.device) for _ in range(2))
+    dk, dv = (torch.empty_strided((B, Hkv, Nk, D), k.stride(), dtype=torch.float32, device=q.device) for _ in range(2))
     ws = torch.empty(lib.fa_bwd_workspace_bytes(B, H, N), dtype=torch.uint8, device=q.device)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
@@ -221,7 +221,7 @@ def flash_attention_backward(
         stream = torch.cuda.current_stream(q.device).cuda_stream
     with torch.cuda.device(q.device):
         st = lib.fa_bwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(),
-                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, H, Hkv, N, D, float(scale), bs, hs,
+                           dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ws.data_ptr(), B, H, Hkv, N, Nk, D, float(scale), bs, hs,
                            kbs, khs, int(bool(is_causal)), _TORCH2FA[q.dtype], stream)
     if st != 0:
         raise FaError(st, lib.fa_last_error().decode())

@@ -54,11 +54,11 @@ def _backward(ctx, grad_o, grad_lse):
     if grad_o is None:
         return None, None, None, None, None
     B, H, N, D = q.shape
-    gqa_ok = k.dim() == 4 and (k.shape[0], k.shape[2], k.shape[3]) == (B, N, D) and H % k.shape[1] == 0
+    gqa_ok = k.dim() == 4 and (k.shape[0], k.shape[3]) == (B, D) and H % k.shape[1] == 0 and not (ctx.is_causal and k.shape[2] < N)
     if not gqa_ok or q.dtype not in (torch.float16, torch.bfloat16) or \
             not load_library().fa_bwd_supported({torch.float16: 1, torch.bfloat16: 2}[q.dtype], D):
         raise FaError(-2, f"no backward kernel for q {tuple(q.shape)} k {tuple(k.shape)} {q.dtype} "
-                          "(fa_bwd_ex: f16 / bf16, Nq == Nk, Hq % Hkv == 0, head_dim 64 or 128)")
+                          "(fa_bwd_ex: f16 / bf16, Hq % Hkv == 0, causal needs Nk >= Nq, head_dim 64 or 128)")
     go = grad_o.to(q.dtype)
     if go.stride() != q.stride():
         go = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device).copy_(go)

@@ -147,14 +147,15 @@ int fa_bwd(const void *q, const void *k, const void *v, const void *o, const voi
            int B, int H, int N, int D, float scale,
            long long batch_stride, long long head_stride,
            int is_causal, int dtype, void *hip_stream);
-/* Grouped-query / multi-query backward (scope row f3 applied to f1; the reference has one head count, kernels.metal:906-920):
- * q, o, d_o, dq are [B,Hq,N,D] under the q strides, k, v, dk, dv are [B,Hkv,N,D] under the kv strides, Hq % Hkv == 0, query head h
- * reads key/value head h / (Hq / Hkv) as in fa_fwd_ex. dK / dV of a key head are the sums over its Hq / Hkv query heads, formed in
- * registers by the one workgroup that owns the key block (no atomics, bitwise reproducible). lse is [B,Hq,N]; workspace is
- * fa_bwd_workspace_bytes(B,Hq,N). With Hkv = Hq and equal strides this is exactly fa_bwd. */
+/* Generalised backward, the counterpart of fa_fwd_ex (scope row f3 applied to f1; the reference's operator is square and has one
+ * head count, kernels.metal:906-920): q, o, d_o, dq are [B,Hq,Nq,D] under the q strides, k, v, dk, dv are [B,Hkv,Nk,D] under the
+ * kv strides, Hq % Hkv == 0, query head h reads key/value head h / (Hq / Hkv); causal is bottom-right aligned (key j visible to
+ * query i iff j <= i + Nk - Nq; needs Nk >= Nq) exactly as in fa_fwd_ex. dK / dV of a key head are the sums over its Hq / Hkv
+ * query heads, formed in registers by the one workgroup that owns the key block (no atomics, bitwise reproducible). lse is
+ * [B,Hq,Nq]; workspace is fa_bwd_workspace_bytes(B,Hq,Nq). With Hkv = Hq, Nk = Nq and equal strides this is exactly fa_bwd. */
 int fa_bwd_ex(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
               float *dq, float *dk, float *dv, void *workspace,
-              int B, int Hq, int Hkv, int N, int D, float scale,
+              int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
               long long q_batch_stride, long long q_head_stride, long long kv_batch_stride, long long kv_head_stride,
               int is_causal, int dtype, void *hip_stream);
 long long fa_bwd_workspace_bytes(int B, int H, int N);

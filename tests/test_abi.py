@@ -108,10 +108,12 @@ def test_ex_and_bwd_reject_bad_strides_and_oversized_grids(fa):
         and b"grid" in lib.fa_last_error()
     assert lib.fa_bwd(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 2, 128, 64, 0.125, -16384, 8192, 0, 2, None) == -1
     # grouped-query backward: Hkv must divide Hq; the key/value strides are checked like the query's
-    assert lib.fa_bwd_ex(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 6, 4, 128, 64, 0.125, 6 * 8192, 8192, 4 * 8192, 8192, 0, 2, None) == -1 \
+    assert lib.fa_bwd_ex(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 6, 4, 128, 128, 64, 0.125, 6 * 8192, 8192, 4 * 8192, 8192, 0, 2, None) == -1 \
         and b"Hkv" in lib.fa_last_error()
-    assert lib.fa_bwd_ex(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 4, 2, 128, 64, 0.125, 4 * 8192, 8192, 2 * 8192, 100, 0, 2, None) == -1 \
+    assert lib.fa_bwd_ex(ok, ok, ok, ok, ok, f, f, f, f, f, 2, 4, 2, 128, 128, 64, 0.125, 4 * 8192, 8192, 2 * 8192, 100, 0, 2, None) == -1 \
         and b"key/value strides" in lib.fa_last_error()
+    # causal with fewer keys than queries would leave empty rows (as in fa_fwd_ex)
+    assert lib.fa_bwd_ex(ok, ok, ok, ok, ok, f, f, f, f, f, 1, 2, 2, 256, 128, 64, 0.125, 2 * 16384, 16384, 2 * 8192, 8192, 1, 2, None) == -2
     assert big > 0
 
 

@@ -99,6 +99,60 @@ def test_backward_grouped_query_heads(fa, oracle_mod, causal, D):
         assert (a.double() - b_).abs().max().item() / b_.abs().max().item() < 3e-2
 
 
+def rect_reference(q, k, v, do, causal):
+    """fp64 gradients of softmax(q k^T / sqrt(D) [+ bottom-right causal mask]) v for q [B,Hq,Nq,D], k / v [B,Hkv,Nk,D]
+    (plain numpy: the C oracle's backward is square). dS = P o (dP - rowsum(dO o O)), kernels.metal:1160-1169."""
+    B, Hq, Nq, D = q.shape
+    Hkv, Nk = k.shape[1], k.shape[2]
+    G = Hq // Hkv
+    q64, do64 = q.astype(np.float64), do.astype(np.float64)
+    ke, ve = (np.repeat(x.astype(np.float64), G, axis=1) for x in (k, v))
+    s_ = np.einsum("bhid,bhjd->bhij", q64, ke) / np.sqrt(D)
+    if causal:
+        i, j = np.arange(Nq)[:, None], np.arange(Nk)[None, :]
+        s_ = np.where(j <= i + (Nk - Nq), s_, -np.inf)
+    p_ = np.exp(s_ - s_.max(-1, keepdims=True))
+    p_ /= p_.sum(-1, keepdims=True)
+    o = np.einsum("bhij,bhjd->bhid", p_, ve)
+    dv = np.einsum("bhij,bhid->bhjd", p_, do64)
+    dp = np.einsum("bhid,bhjd->bhij", do64, ve)
+    ds = p_ * (dp - (do64 * o).sum(-1, keepdims=True)) / np.sqrt(D)
+    dq = np.einsum("bhij,bhjd->bhid", ds, ke)
+    dk = np.einsum("bhij,bhid->bhjd", ds, q64)
+    return dq, dk.reshape(B, Hkv, G, Nk, D).sum(2), dv.reshape(B, Hkv, G, Nk, D).sum(2)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_rectangular(fa, oracle_mod, causal, D):
+    """fa_bwd_ex with Nq != Nk (the counterpart of fa_fwd_ex): cross-attention shapes, and bottom-right aligned causal masks."""
+    import torch
+
+    dtype = "bf16"
+    cases = [(1, 2, 2, 100, 260), (2, 4, 2, 64, 129), (1, 2, 1, 1, 200), (1, 1, 1, 130, 131)]
+    if not causal:
+        cases += [(1, 2, 2, 260, 100), (1, 4, 1, 200, 1)]  # more queries than keys: non-causal only (fa_fwd_ex's rule)
+    for (B, Hq, Hkv, Nq, Nk) in cases:
+        q, _, _ = make_qkv(oracle_mod, B, Hq, Nq, D, dtype)
+        _, k, v = make_qkv(oracle_mod, B, Hkv, Nk, D, dtype)
+        do = oracle_mod.round_to(oracle_mod.init_random(B * Hq * Nq * D, 45).reshape(B, Hq, Nq, D), dtype)
+        qd, kd, vd, dod = (to_dev(x, dtype) for x in (q, k, v, do))
+        o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal)
+        dq, dk, dv = fa.flash_attention_backward(qd, kd, vd, o, dod, lse, is_causal=causal)
+        torch.cuda.synchronize()
+        assert dq.shape == qd.shape and dk.shape == kd.shape and dv.shape == kd.shape
+        for name, g, ref in zip(("dq", "dk", "dv"), (dq, dk, dv), rect_reference(q, k, v, do, causal)):
+            g = g.cpu().numpy()
+            assert np.isfinite(g).all(), (name, B, Hq, Hkv, Nq, Nk)
+            assert rel(g, ref) < TOL[dtype], (name, causal, B, Hq, Hkv, Nq, Nk, rel(g, ref))
+    if causal:
+        x = torch.zeros(1, 1, 256, D, dtype=torch.bfloat16, device="cuda")
+        y = torch.zeros(1, 1, 128, D, dtype=torch.bfloat16, device="cuda")
+        with pytest.raises(fa.FaError) as e:
+            fa.flash_attention_backward(x, y, y, x, x, torch.zeros(1, 1, 256, device="cuda"), is_causal=True)
+        assert e.value.status == -2
+
+
 def test_backward_known_answers(fa, oracle_mod):
     import torch
 
