@@ -225,7 +225,13 @@ int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse, 
   p.batch_stride = q_batch_stride; p.head_stride = q_head_stride;
   p.is_causal = is_causal ? 1 : 0;
   p.Nk = Nk; p.Hkv = Hkv; p.kv_batch_stride = kv_batch_stride; p.kv_head_stride = kv_head_stride;
-  hipError_t e = fa::launch_mfma(p, dtype, (hipStream_t)hip_stream);
+  // few query blocks against many keys (decode steps, short prompts): the AUTO rule of fa_fwd for small grids -- the keys of every
+  // 32-row block are split over the waves of a workgroup (the split-KV kernel takes the same Params: Nk, key/value heads).
+  // head_dim 64 only: there it is 1.2-3x faster than the 128-row kernel at every key length (32 heads x 1 query x 16384 keys:
+  // 165 -> 55 us), at head_dim 128 its four private 32-KiB tiles make it 2-4x SLOWER (profiles/r03/decode_steps_splitkv_rule.log)
+  const long long blocks128 = (long long)B * Hq * ((Nq + 127) / 128);
+  const bool small_grid = D == 64 && fa::splitkv_supported(dtype, D) && Nk > 64 && blocks128 <= 64;
+  hipError_t e = small_grid ? fa::launch_splitkv(p, dtype, (hipStream_t)hip_stream) : fa::launch_mfma(p, dtype, (hipStream_t)hip_stream);
   if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_fwd_ex: launch failed: %s", hipGetErrorString(e));
   return FA_OK;
 }

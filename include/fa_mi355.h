@@ -120,8 +120,10 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
  *   q, o  [B, Hq, Nq, D] with q_batch_stride / q_head_stride;  k, v  [B, Hkv, Nk, D] with kv strides
  *   query head h attends to key/value head h / (Hq / Hkv)   (Hq % Hkv == 0)
  *   causal is bottom-right aligned: key j is visible to query i iff j <= i + (Nk - Nq); needs Nk >= Nq
- *   lse [B, Hq, Nq]. Matrix-core kernel only (f16 / bf16: D = 32, 64, 96, 128, 256; fp8 inputs: D = 64, 128, 256).
- * With Hkv = Hq, Nk = Nq and equal strides this is exactly fa_fwd(..., FA_VARIANT_MFMA).
+ *   lse [B, Hq, Nq]. Matrix-core kernels only (f16 / bf16: D = 32, 64, 96, 128, 256; fp8 inputs: D = 64, 128, 256): the 128-row
+ *   kernel, or -- at most 64 blocks of 128 query rows against more than 64 keys, e.g. decode steps, D = 64 -- the
+ *   split-KV kernel, as FA_VARIANT_AUTO chooses for fa_fwd.
+ * With Hkv = Hq, Nk = Nq and equal strides this is fa_fwd(..., FA_VARIANT_MFMA) (or ..._SPLITKV under that rule).
  */
 int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse,
               int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,

@@ -342,7 +342,9 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
         (2, 8, 2, 200, 200, 64, True), (1, 8, 1, 130, 130, 64, False), (2, 4, 4, 64, 300, 64, True),
         (1, 6, 3, 1, 257, 64, True), (1, 4, 2, 100, 37, 64, False), (1, 8, 2, 129, 512, 128, True),
         (1, 2, 1, 77, 77, 128, True), (1, 16, 4, 33, 1000, 64, True), (1, 4, 2, 70, 150, 32, True),
-        (1, 4, 1, 65, 65, 96, False), (1, 2, 2, 40, 300, 256, True)]
+        (1, 4, 1, 65, 65, 96, False), (1, 2, 2, 40, 300, 256, True),
+        (2, 32, 8, 1, 1000, 128, True), (1, 8, 8, 1, 65, 64, False), (4, 32, 8, 16, 700, 64, True),  # decode steps / short chunks
+        (3, 32, 4, 130, 260, 64, True), (1, 72, 8, 128, 128, 128, True)]  # more than 64 blocks: the 128-row kernel
     for (B, Hq, Hkv, Nq, Nk, D, causal) in cases:
         q = oracle_mod.round_to(oracle_mod.init_random(B * Hq * Nq * D, int(rng.integers(1, 1 << 20))).reshape(B, Hq, Nq, D), dtype)
         k = oracle_mod.round_to(oracle_mod.init_random(B * Hkv * Nk * D, int(rng.integers(1, 1 << 20))).reshape(B, Hkv, Nk, D), dtype)
@@ -351,16 +353,19 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
         o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal)
         torch.cuda.synchronize()
         o64, l64 = oracle_mod.attn_fwd_ex_f64(q, k, v, causal)
+        # which kernel fa_fwd_ex runs (include/fa_mi355.h): the split-KV kernel for at most 64 blocks of 128 query rows against
+        # more than 64 keys at head_dim 64 (it scales every score in fp32), else the 128-row kernel (pre-scaled operand)
+        small = D == 64 and Nk > 64 and B * Hq * ((Nq + 127) // 128) <= 64
+        pre = D <= 128 and not small
         assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype], (B, Hq, Hkv, Nq, Nk, D, causal)
-        assert np.abs(lse.cpu().numpy() - l64).max() < lse_tol(dtype, D <= 128, q, k)
-        if D <= 128:  # the generalised entry runs the 128-row kernel with the pre-scaled operand: strict vs the oracle on Q~
+        assert np.abs(lse.cpu().numpy() - l64).max() < lse_tol(dtype, pre, q, k), (B, Hq, Hkv, Nq, Nk, D, causal)
+        if pre:  # strict vs the oracle on the operand the kernel really multiplies
             o64, l64 = oracle_mod.attn_fwd_ex_f64(effective_q(oracle_mod, q, dtype), k, v, causal, LN2)
             assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype] and np.abs(lse.cpu().numpy() - l64).max() < 1e-4
-        if Nq == Nk:  # GQA == MHA on repeated K/V heads, bit for bit
+        if Nq == Nk:  # GQA == MHA on repeated K/V heads, bit for bit, through the same kernel by name
             g = Hq // Hkv
-            # (variant "mfma": the generalised entry always runs the 128-row kernel; "auto" may pick another one for a small grid)
             o2, l2 = fa.flash_attention_forward(qd, kd.repeat_interleave(g, 1).contiguous(), vd.repeat_interleave(g, 1).contiguous(),
-                                                is_causal=causal, variant="mfma")
+                                                is_causal=causal, variant="mfma_splitkv" if small else "mfma")
             assert torch.equal(o, o2) and torch.equal(lse, l2)
     if dtype == "bf16":  # the same generalised path with fp8 (e4m3) inputs: equal to bf16 on the same values up to fp32 summation order
         q = oracle_mod.round_to(oracle_mod.init_random(2 * 8 * 96 * 64, 5).reshape(2, 8, 96, 64) * 2, "fp8")
