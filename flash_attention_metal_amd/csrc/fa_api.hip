@@ -92,7 +92,10 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   // small grids: fewer 128-row workgroups than a quarter of the CUs (or half, when each would walk >= 32 tiles):
   // split the keys of every 32-row block over the waves of a workgroup instead (config 2: 15.9 -> 10.6 us)
   const long long blocks128 = (long long)B * H * ((N + 127) / 128);
-  if (fa::splitkv_supported(dtype, D) && N > 64 && blocks128 <= 64) return FA_VARIANT_MFMA_SPLITKV;
+  // (head_dim 64 only: the head_dim-128 instantiation needs more than the 256 registers its eight-wave workgroup leaves a wave and
+  // spills 820 B -- 8 heads x 1024: 73 us against 17-20 us for the kernels below, profiles/r03/ab_d128_small_grids.log; it stays
+  // reachable by name)
+  if (D == 64 && fa::splitkv_supported(dtype, D) && N > 64 && blocks128 <= 64) return FA_VARIANT_MFMA_SPLITKV;
   // head_dim 64, 16-bit inputs, at most two 64-row workgroups per CU: 64-row blocks whose wave pairs take the even / odd
   // tiles -- twice the workgroups and half the sequential tiles (h=8, N=2048 causal: 20.0 (eight-wave form) -> 17.9 us;
   // 64 heads x 256: 6.6 -> 5.9 us; profiles/r03/ab_h64s2.log)

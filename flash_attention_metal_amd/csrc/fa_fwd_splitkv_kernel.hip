@@ -22,7 +22,9 @@
 namespace fa {
 
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(512, 1) void fwd_splitkv_kernel(Params p) {
+// (head_dim 128 never runs more than four waves -- splitkv_waves: LDS -- so its register cap is 512, not 256: compiled for
+//  eight it spilled 820 B per lane and ran 3-4x slower than the kernels it was chosen over, profiles/r03/ab_d128_small_grids.log)
+__global__ __launch_bounds__((D == 64 ? 512 : 256), 1) void fwd_splitkv_kernel(Params p) {
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;

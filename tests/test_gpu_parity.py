@@ -550,7 +550,8 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
         (1, 200, 128, 64, "f16", True, "mfma"),            # N < 256: plain kernel
         (1, 40, 512, 64, "fp8", True, "mfma_split2"),      # fp8 keeps the eight-wave form (160 blocks of 128 rows)
         (2, 3, 64, 64, "f16", True, "mfma"),               # N <= 64: a single tile, never split-KV
-        (1, 2, 4096, 128, "bf16", True, "mfma_splitkv"),   # head_dim 128, 64 blocks
+        (1, 2, 4096, 128, "bf16", True, "mfma_split2"),    # head_dim 128, 64 blocks: never split-KV (its head_dim-128 build spills)
+        (1, 8, 256, 128, "bf16", False, "mfma"),           # head_dim 128, 16 blocks, N < 512: the plain kernel
         (1, 16, 2048, 128, "bf16", True, "mfma_split2"),   # 256 blocks of 128 rows, N < 4096
         (1, 32, 4096, 128, "bf16", True, "mfma"),          # long head_dim-128 sequences: the 128-row kernel (round 2: paired-block)
         (1, 4, 300, 96, "bf16", True, "mfma"),             # head dims only the 128-row kernel has

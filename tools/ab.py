@@ -12,6 +12,7 @@ SHAPES = {  # name: (B, H, N, D, dtype, causal)
     "c5": (4, 16, 8192, 64, "fp8", 1), "c5bf": (4, 16, 8192, 64, "bf16", 1), "c5d128": (2, 16, 8192, 128, "fp8", 1), "c5d128bf": (2, 16, 8192, 128, "bf16", 1), "c8k": (4, 16, 8192, 64, "bf16", 1), "c1k": (4, 16, 1024, 64, "bf16", 1), "c2bf": (1, 8, 1024, 64, "bf16", 0), "c2c": (1, 8, 1024, 64, "bf16", 1), "h8n2k": (1, 8, 2048, 64, "bf16", 1), "h16n512": (1, 16, 512, 64, "bf16", 1), "h32n1k": (1, 32, 1024, 64, "bf16", 1), "c512": (4, 16, 512, 64, "bf16", 1), "c256": (4, 16, 256, 64, "bf16", 1), "c128": (4, 16, 128, 64, "bf16", 1), "c2k": (4, 16, 2048, 64, "bf16", 1), "d128nc": (1, 32, 8192, 128, "bf16", 0),
     "c3x4": (16, 16, 4096, 64, "bf16", 1), "c3x3": (12, 16, 4096, 64, "bf16", 1), "c3x2": (8, 16, 4096, 64, "bf16", 1), "c3h": (2, 16, 4096, 64, "bf16", 1), "c3h48": (3, 16, 4096, 64, "bf16", 1),
     "d128c1k": (2, 32, 1024, 128, "bf16", 1), "d128c2k": (2, 32, 2048, 128, "bf16", 1), "d128c4k": (1, 32, 4096, 128, "bf16", 1),
+    "d128h8n1k": (1, 8, 1024, 128, "bf16", 0), "d128h8n1kc": (1, 8, 1024, 128, "bf16", 1), "d128h8n2kc": (1, 8, 2048, 128, "bf16", 1), "d128h16n512c": (1, 16, 512, 128, "bf16", 1), "d128h32n256": (1, 32, 256, 128, "bf16", 0), "d128h8n4kc": (1, 8, 4096, 128, "bf16", 1),
     "d128c8k": (1, 32, 8192, 128, "bf16", 1), "d128c4k8h": (1, 8, 4096, 128, "bf16", 1), "d128nc2k": (2, 32, 2048, 128, "bf16", 0),
 }
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--shapes", default="c3,nc8k,c16k")
