@@ -126,3 +126,33 @@ def test_backward_kernels_fit_their_occupancy_without_scratch():
             assert vg + ag <= 168 and scratch == 0 and occ == 3, (name, vg, ag, scratch, occ)
         else:
             assert vg + ag <= 256 and scratch <= 32 and occ == 2, (name, vg, ag, scratch, occ)
+
+
+def test_forward_kernels_auto_can_dispatch_do_not_spill():
+    # Every forward kernel FA_VARIANT_AUTO / fa_fwd_ex can launch, compiled with the Makefile's flags: no scratch, except the
+    # documented 16-28 B of the head_dim-256 kernel. The head_dim-128 split-KV kernel is reachable BY NAME only since
+    # round 3 found it spilling 820 B under the eight-wave register cap while AUTO was choosing it for small grids
+    # (profiles/r03/ab_d128_small_grids.log): it is held to the 172 B it has left under its four-wave cap.
+    import re
+
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    procs = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for stem in ("fa_mfma_kernel", "fa_fwd_splitkv_kernel"):
+            src = os.path.join(ROOT, "flash_attention_metal_amd", "csrc", stem + ".hip")
+            procs[stem] = subprocess.Popen([hipcc] + makefile_flags(stem) + ["--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", src,
+                                            "-o", "/dev/null"], cwd=tmp, stderr=subprocess.PIPE, text=True)
+        logs = {stem: p.communicate()[1] for stem, p in procs.items()}
+        assert all(p.returncode == 0 for p in procs.values()), {k: v[-1500:] for k, v in logs.items()}
+    rows = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", "".join(logs.values()), re.S)
+    seen = {n: int(sc) for n, sc in rows if "fwd_" in n}
+    assert len(seen) >= 50, len(seen)
+    for name, scratch in seen.items():
+        if "splitkv" in name and "Li128E" in name and "FP8" not in name:
+            assert scratch <= 172, (name, scratch)
+        elif "Li256E" in name:
+            assert scratch <= 32, (name, scratch)
+        else:
+            assert scratch == 0, (name, scratch)
