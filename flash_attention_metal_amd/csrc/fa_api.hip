@@ -83,7 +83,6 @@ int fa_resolve_variant(int dtype, int D) {
 // grids far smaller than the chip, the 64-row two-split form and the eight-wave form of the 128-row kernel on grids of up to
 // two / one workgroup(s) per CU; everywhere else the 128-row kernel is fastest.
 int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal) {
-  (void)is_causal;
   const int v = fa_resolve_variant(dtype, D);
   if (v != FA_VARIANT_MFMA) return v;
   // (round 2 sent long head_dim-128 sequences to the paired-block kernel; since the 128-row kernel stages its tiles by
@@ -104,6 +103,12 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   // up to one 128-row workgroup per CU: the block's tiles are the critical path -- eight waves, even / odd tiles
   // (h=32, N=1024 causal: 16.1 -> 14.2 us; h=8, N=2048: 27.3 -> 22.0 us, split-KV 25.1)
   if (fa::mfma_split2_supported(dtype, D) && N >= 512 && blocks128 <= 256) return FA_VARIANT_MFMA_SPLIT2;
+  // causal, two workgroups' worth of blocks per CU of which half are light: the heaviest block's 32+ tiles are still the critical
+  // path (32 heads x 2048: 28.9 -> 25.9 us at head_dim 64, 45.8 -> 42.5 at 128, fp8 29.3 -> 24.6; at N = 1024 the plain kernel
+  // wins again; profiles/r03/auto_check.log)
+  // (fp8 inputs at head_dim 64 already from N = 1024: 64 heads x 1024, 16.7 -> 14.7 us)
+  const int n_min = (dtype == FA_DTYPE_FP8_E4M3 && D == 64) ? 1024 : 2048;
+  if (fa::mfma_split2_supported(dtype, D) && is_causal && N >= n_min && blocks128 <= 512) return FA_VARIANT_MFMA_SPLIT2;
   return FA_VARIANT_MFMA;
 }
 

@@ -553,10 +553,14 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
         (1, 2, 4096, 128, "bf16", True, "mfma_split2"),    # head_dim 128, 64 blocks: never split-KV (its head_dim-128 build spills)
         (1, 8, 256, 128, "bf16", False, "mfma"),           # head_dim 128, 16 blocks, N < 512: the plain kernel
         (1, 16, 2048, 128, "bf16", True, "mfma_split2"),   # 256 blocks of 128 rows, N < 4096
+        (1, 32, 2048, 64, "bf16", True, "mfma_split2"),    # causal, 512 blocks, N >= 2048: still the eight-wave form
+        (1, 32, 2048, 64, "bf16", False, "mfma"),          # ... not without the mask
+        (1, 64, 1024, 64, "bf16", True, "mfma"),           # ... and not at N = 1024
         (1, 32, 4096, 128, "bf16", True, "mfma"),          # long head_dim-128 sequences: the 128-row kernel (round 2: paired-block)
         (1, 4, 300, 96, "bf16", True, "mfma"),             # head dims only the 128-row kernel has
         (1, 8, 1024, 64, "fp8", True, "mfma_splitkv"),
-        (1, 40, 1024, 64, "fp8", True, "mfma"),
+        (1, 40, 1024, 64, "fp8", True, "mfma_split2"),     # fp8, causal, 320 blocks, N >= 1024: the eight-wave form
+        (1, 80, 1024, 64, "fp8", True, "mfma"),            # 640 blocks: the plain kernel
     ]
     for (B, H, N, D, dtype, causal, want) in cases:
         fdt = fa.DTYPES[{"fp8": "fp8_e4m3"}.get(dtype, dtype)]
