@@ -42,7 +42,9 @@
 #define FA_PRESCALE 1  // 1 (f16/bf16): Q~ = round(scale.log2e.Q) once per block and -m (log2 units) as the C operand of each score chain: P = exp2(S') with no FMA
 #endif
 #ifndef FA_VPRE_HALF
-#define FA_VPRE_HALF 1  // 1: only the first 32 keys' V^T fragments are prefetched under the QK^T MFMAs, the second half under the first half's PV MFMAs (-16 live registers)
+#define FA_VPRE_HALF 0  // 1: only the first 32 keys' V^T fragments are prefetched under the QK^T MFMAs, the second half under the first half's PV MFMAs (-16 live
+                        // registers: needed while K/V were staged through registers; with LDS-DMA staging the full prefetch fits -- 162-164 VGPR, no scratch --
+                        // and is 0.5-0.9 % faster, profiles/r03/ab_knobs_final_build.log)
 #endif
 #ifndef FA_MFMA_DMA
 #define FA_MFMA_DMA 1  // 1 (f16/bf16, head_dim 32/64/128): K/V tiles go global -> LDS by LDS-DMA (buffer_load ... lds), no staging registers, no
