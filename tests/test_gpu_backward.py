@@ -265,3 +265,41 @@ def test_torch_op_autograd_matches_sdpa(fa, oracle_mod, dtype, causal):
     with pytest.raises(Exception):  # no gradient through the LSE output
         lse2.sum().backward()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_backward_padded_strides_and_larger_logits(fa, oracle_mod, D):
+    """Tensors that are views into padded buffers (head stride > N*D, batch stride > H*head stride; Q and K/V padded differently)
+    and inputs three times larger than the benchmark's (|score| up to ~20): the strides reach the kernels through fa_bwd_ex, the
+    row constants -LSE*log2e ride in the accumulators at that magnitude."""
+    import torch
+
+    dtype, causal = "bf16", True
+    B, Hq, Hkv, N = 2, 4, 2, 200
+    q, _, _ = make_qkv(oracle_mod, B, Hq, N, D, dtype)
+    _, k, v = make_qkv(oracle_mod, B, Hkv, N, D, dtype)
+    q, k = (oracle_mod.round_to(x * 3.0, dtype) for x in (q, k))
+    do = oracle_mod.round_to(oracle_mod.init_random(B * Hq * N * D, 45).reshape(B, Hq, N, D), dtype)
+
+    def padded(x, extra_rows, extra_heads):
+        b, h, n, d = x.shape
+        buf = torch.full((b, h + extra_heads, n + extra_rows, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+        view = buf[:, :h, :n]
+        view.copy_(to_dev(x, dtype))
+        return view
+
+    qd, dod = padded(q, 8, 1), padded(do, 8, 1)
+    kd, vd = padded(k, 24, 0), padded(v, 24, 0)
+    assert not qd.is_contiguous() and qd.stride() == dod.stride() and kd.stride() == vd.stride() and qd.stride(1) != kd.stride(1)
+    o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal)
+    o_p = padded(o.float().cpu().numpy(), 8, 1)  # O in a buffer padded like Q's (the backward wants q, o, d_o under one stride pair)
+    dq, dk, dv = fa.flash_attention_backward(qd, kd, vd, o_p, dod, lse, is_causal=causal)
+    torch.cuda.synchronize()
+    assert dq.stride() == qd.stride() and dk.stride() == kd.stride()
+    ke, ve = (np.ascontiguousarray(np.repeat(x, Hq // Hkv, axis=1)) for x in (k, v))
+    rq, rk, rv = oracle_mod.attn_bwd_f64(q, ke, ve, do, causal)
+    rk, rv = (x.reshape(B, Hkv, Hq // Hkv, N, D).sum(2) for x in (rk, rv))
+    for name, g, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        g = g.cpu().numpy()
+        assert np.isfinite(g).all(), name  # (the NaN padding was never read)
+        assert rel(g, ref) < TOL[dtype], (name, D, rel(g, ref))
