@@ -46,6 +46,12 @@
                         // registers: needed while K/V were staged through registers; with LDS-DMA staging the full prefetch fits -- 162-164 VGPR, no scratch --
                         // and is 0.5-0.9 % faster, profiles/r03/ab_knobs_final_build.log)
 #endif
+#ifndef FA_MAIN_OCC4
+#define FA_MAIN_OCC4 1  // 1: the plain 128-row kernel at head_dim 64 (16-bit inputs, pre-scaled operand) gives up the V^T prefetch below and
+                        // fits 128 registers: FOUR workgroups per CU instead of three. Config 3 +2.6 %, N=8192 +2.7 %, non-causal N=4096
+                        // +1.6 %, N<=2048 -0.3..-1.7 % (profiles/r03/ab_four_waves_per_simd.log). Round 3 first tried four with the prefetch
+                        // in place and spilled 150-210 B; the split / 64-row / exact forms keep the prefetch and three.
+#endif
 #ifndef FA_MFMA_DMA
 #define FA_MFMA_DMA 1  // 1 (f16/bf16, head_dim 32/64/128): K/V tiles go global -> LDS by LDS-DMA (buffer_load ... lds), no staging registers, no
                        // ds_write: config 3 +6.7 %, head_dim 128 +9..11 %, bit-identical outputs (profiles/r03/ab_mfma_lds_dma.log); 0 = register staging
@@ -79,6 +85,12 @@ constexpr bool prescale_applies() {
 // ROWS: query rows per workgroup, 128 (four row groups of 32 = four waves per split) or 64 (two): "h64s2" = 64 rows x 2 splits
 // is a four-wave workgroup whose wave pairs take the even / odd KV tiles -- twice the workgroups and half the sequential
 // tiles of a block, for causal grids whose critical path is the heaviest q block (N <= 2048 at 64 heads).
+// the instantiations of the plain kernel that run four workgroups per CU (FA_MAIN_OCC4)
+template <typename Tag, int D, bool PRESC>
+constexpr bool main_kernel_occ4() {
+  return (FA_MAIN_OCC4 != 0) && D == 64 && PRESC && prescale_applies<Tag, D>();
+}
+
 template <typename Tag, int D, bool CAUSAL, int SPLIT, bool PRESC, int ROWS = BM>
 __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   constexpr int RW = ROWS / WM;   // row groups = waves per split
@@ -98,7 +110,8 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
   constexpr int GRB = D * GB;               // global row bytes
   constexpr int GTILE = BN * GRB;           // global bytes of one K (or V) tile
   constexpr int NCH = BN * (GRB / 16) / ST;  // staged 16-byte global chunks per thread per tile
-  constexpr bool VPRE = (D == 64) && !IS_FP8;  // prefetch V^T fragments under the QK^T MFMAs
+  constexpr bool MAIN4 = (FA_MAIN_OCC4 != 0) && main_kernel_occ4<Tag, D, PRESC>() && SPLIT == 1 && ROWS == BM;
+  constexpr bool VPRE = (D == 64) && !IS_FP8 && !MAIN4;  // prefetch V^T fragments under the QK^T MFMAs
   // Pre-scaled operand (f16/bf16): the Q fragments are multiplied by c = scale.log2(e) and rounded back to the input
   // type ONCE per block, and the running reference -m (log2 units) is the C operand of the first MFMA of every score
   // chain, so the matrix core hands out S' = c.q.k - m and P = exp2(S') needs no v_fma (kernels.metal:763-771 scales
@@ -720,7 +733,7 @@ __device__ __forceinline__ void fwd_mfma_body(const Params &p) {
 }
 
 template <typename Tag, int D, bool CAUSAL, bool PRESC>
-__global__ __launch_bounds__(NTHREADS, (D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
+__global__ __launch_bounds__(NTHREADS, (main_kernel_occ4<Tag, D, PRESC>() ? 4 : D <= 64 ? 3 : D <= 128 ? 2 : 1)) void fwd_mfma_kernel(Params p) {
   fwd_mfma_body<Tag, D, CAUSAL, 1, PRESC>(p);
 }
 
