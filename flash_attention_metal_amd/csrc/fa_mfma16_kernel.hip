@@ -1,0 +1,431 @@
+// fa_mfma16_kernel.hip -- the operator on v_mfma_f32_16x16x32_{bf16,f16} (variant "mfma16").
+//
+// Same math and the same workgroup shape as fa_mfma_kernel.hip (replaces /root/reference/kernels.metal:600-883: tiled
+// QK^T -> online softmax -> PV, causal predicate `key > query -> masked` kernels.metal:748, L = m + ln(l)
+// kernels.metal:862-864), but every matrix product runs on the 16x16x32 instruction instead of 32x32x16. Why a second
+// kernel for the same work: on random data the chip is power-limited under these loops and holds a higher clock on
+// the 16x16x32 shape (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15x the FLOP/s of the 32x32x16 loop at equal
+// cycles per FLOP; cdna_hip_programming.md rule 28) -- so cycles per FLOP do not decide which is faster, wall does.
+//
+// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head); a wave owns 32 rows = TWO 16-row query tiles,
+// so every K / V^T fragment read from LDS still feeds two MFMAs -- LDS traffic per FLOP equals the 32x32x16 kernel's):
+//   * S^T = K.Q^T per 16 keys x 16 queries ("swapped" product): lane (c = lane & 15, g = lane >> 4) holds the scores of
+//     query c of each query tile against keys 16kt + 4g + i (i = register) -- a lane serves TWO query rows, 16 scores each
+//     per 64-key tile; row max / row sum are in-register reductions, the four lanes of a row (g = 0..3) meet only on the
+//     rare exact path and in the epilogue
+//   * pre-scaled query operand Q~ = round(scale.log2e.Q) and the running reference -m as the C operand of the first MFMA
+//     of every score chain (4 registers per query tile instead of 16): P = exp2(S') with no FMA; the row sums decide
+//     whether m is stale (sum-triggered deferred max, threshold 2^8) exactly as in fa_mfma_kernel.hip
+//   * P^T feeds PV straight from the score registers: the B operand's k index (8g + j) is key 16(j >> 2) + 4g + (j & 3) of a
+//     32-key step, and V^T is read with ds_read_b64_tr_b16 in the same order (V stays row-major in HBM and LDS)
+//   * K/V tiles of 64 keys double-buffered in LDS, global -> LDS by LDS-DMA with the chunk swizzle on the source address;
+//     one barrier per tile; images: K chunk ^ ((row >> 1) & 7), V chunk ^ (((row >> 1) & 3) << 1) at head_dim 64 (both
+//     conflict-free for these reads: checked on the CPU by tests/test_lds_images.py)
+//   * epilogue: O tile -> LDS -> whole rows, 16 B per lane; LSE = m.ln2 + ln(l)
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "fa_mfma_common.h"
+
+#ifndef FA16_DEFER_THR
+#define FA16_DEFER_THR 8.0f  // log2 units: P <= 2^8 between rescales
+#endif
+#ifndef FA16_LAK
+#define FA16_LAK 2  // K fragments are read this many fragments (each feeds two MFMAs) ahead of their use
+#endif
+#ifndef FA16_LAV
+#define FA16_LAV 2  // ... and V^T fragments
+#endif
+#ifndef FA16_PRIO
+#define FA16_PRIO 1  // 1: wave priority raised around the MFMA clusters
+#endif
+#ifndef FA16_OCC
+#define FA16_OCC 4  // workgroups per CU the head_dim-64 kernel is compiled for (128 registers)
+#endif
+
+namespace fa {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename Tag> struct MT16;
+template <> struct MT16<BF16> {
+  using elem = __bf16;
+  using vec8 = bf16x8;
+  __device__ static __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct MT16<F16> {
+  using elem = _Float16;
+  using vec8 = f16x8;
+  __device__ static __forceinline__ f32x4 mfma(vec8 a, vec8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+// value of lane ^ 16 / lane ^ 32 (rare path and epilogue only: ds_bpermute, no LDS memory)
+__device__ __forceinline__ float xlane(float x, int mask) { return __shfl_xor(x, mask, 64); }
+
+template <typename Tag, int D, bool CAUSAL>
+__device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
+  using M = MT16<Tag>;
+  using vec8 = typename M::vec8;
+  using elem = typename M::elem;
+  constexpr int RW = BM / WM;      // waves
+  constexpr int RB = D * 2;        // row bytes (global and LDS)
+  constexpr int CPR = D / 8;       // 16-byte chunks per row
+  constexpr int KS = D / 32;       // 32-wide k-steps of the score product
+  constexpr int DT = D / 16;       // 16-wide d tiles of O^T
+  constexpr int KT = BN / 16;      // 16-key tiles per KV tile
+  constexpr int TILE = BN * RB;    // bytes of one K (or V) tile
+  static_assert(D == 64 || D == 128, "head dims of the 16x16x32 kernel");
+
+  extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+  lds_char *smem = (lds_char *)smem_generic;
+  lds_char *Kbuf = smem;             // [2][BN][RB], chunks swizzled
+  lds_char *Vbuf = smem + 2 * TILE;  // [2][BN][RB], chunks swizzled
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int c = lane & 15;  // query within a query tile / key row within a key tile / d within a d tile
+  const int g = lane >> 4;  // 16-lane group
+
+  int bh, qb;
+  map_block<CAUSAL>(blockIdx.x, p, bh, qb);
+  long long base, base_kv;
+  head_bases(bh, p, base, base_kv);
+  const int coff = p.Nk - p.N;  // causal, Nq != Nk: bottom-right aligned (key j visible to query i iff j <= i + coff)
+  const int q0 = qb * BM;
+  const int qw0 = q0 + wave * WM;
+
+  const unsigned head_bytes = (unsigned)p.N * RB, kv_head_bytes = (unsigned)p.Nk * RB;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.q + base * 2), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.k + base_kv * 2), 0, kv_head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.v + base_kv * 2), 0, kv_head_bytes, 0x00020000);
+
+  // ---- Q fragments (B operand of K.Q^T): lane (c, g) holds Q[qw0 + 16qt + c][32ks + 8g .. +7]; rows >= N read as zero
+  vec8 qf[2][KS];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)(qw0 + 16 * qt + c) * RB + 64 * ks + 16 * g, 0, 0);
+      qf[qt][ks] = __builtin_bit_cast(vec8, t);
+    }
+
+  // ---- per-lane LDS addresses (absolute, opaque to hipcc: the dynamic-LDS base is a link-time constant it cannot fold)
+  // K: ds_read_b128 of row (16kt + c), chunk (4ks + g); the swizzle depends on c only
+  const int kx = (D == 64) ? ((c >> 1) & 7) : c;
+  const lds_char *kptr[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kptr[ks] = Kbuf + c * RB + (((4 * ks + g) ^ kx) << 4);
+    asm volatile("" : "+v"(kptr[ks]));
+  }
+  // V: transposed read; lane 4q + pp of a 16-lane group addresses row (.. + 4g + q), columns 16dt + 4pp .. +3
+  const int vq = c >> 2, vp = c & 3;
+  const int vrow = 4 * g + vq;
+  const int vx = (D == 64) ? (((vrow >> 1) & 3) << 1) : ((vrow & 7) << 1);
+  const lds_char *vptr[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) {
+    vptr[dt] = Vbuf + vrow * RB + ((((2 * dt) ^ vx) + (vp >> 1)) << 4) + 8 * (vp & 1);
+    asm volatile("" : "+v"(vptr[dt]));
+  }
+
+  const int kv_end = CAUSAL ? min(p.Nk, q0 + BM + coff) : p.Nk;
+  const int nT = (kv_end + BN - 1) / BN;
+
+  // ---- LDS-DMA staging: wave w moves the 1-KiB pieces w, w + 4, ... of each tile; inside a piece the LDS image is
+  // lane-linear, so the chunk swizzle sits on the SOURCE address (one per-lane offset for K, one for V)
+  constexpr int RPP = 1024 / RB;        // rows per piece
+  constexpr int NPW = (BN / RPP) / RW;  // pieces per wave, tile and operand
+  static_assert((RW * RPP) % 16 == 0, "the piece stride must keep the swizzle");
+  unsigned dma_kvo, dma_vvo;
+  {
+    const int row = wave * RPP + lane / CPR, pc = lane % CPR;
+    const int skx = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    const int svx = (D == 64) ? (((row >> 1) & 3) << 1) : ((row & 7) << 1);
+    dma_kvo = (unsigned)(row * RB + ((pc ^ skx) << 4));
+    dma_vvo = (unsigned)(row * RB + ((pc ^ svx) << 4));
+  }
+  auto stage_dma = [&](int t, int buf) {  // tile t -> buffer buf (hipcc does not count these loads: the caller waits vmcnt(0))
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const unsigned soff = (unsigned)t * TILE + j * (RW * 1024);
+      const unsigned lk = (unsigned)(__UINTPTR_TYPE__)Kbuf + buf * TILE + (wave + RW * j) * 1024;
+      const unsigned lv = (unsigned)(__UINTPTR_TYPE__)Vbuf + buf * TILE + (wave + RW * j) * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dma_kvo), "s"(rk), "s"(soff) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lv), "v"(dma_vvo), "s"(rv), "s"(soff) : "memory");
+    }
+  };
+
+  f32x4 oacc[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) oacc[dt][qt][i] = 0.0f;
+  float m[2] = {-INFINITY, -INFINITY};  // reference max of row (16qt + c), log2 units (may lag the true max by < 2^THR)
+  float l[2] = {0.0f, 0.0f};            // this lane's share of the row sums
+  const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
+  // -m in the 4 registers of a tuple per query tile = the C operand of each score chain's first MFMA (0 until the first
+  // tile has set m: the first tile's scores come out raw and go through the exact path)
+  f32x4 negm[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) negm[qt][i] = 0.0f;
+    asm volatile("" : "+v"(negm[qt]));  // opaque: else hipcc re-materialises the splat in front of every MFMA
+  }
+
+  stage_dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Q~ = round(c.Q), once per block; retire the Q loads HERE (hipcc otherwise carries them into the loop as "possibly pending")
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (elem)((float)qf[qt][ks][j] * c2);
+      asm volatile("" : "+v"(qf[qt][ks]));
+    }
+  __syncthreads();
+
+  const float sum_thr = __builtin_exp2f(FA16_DEFER_THR);
+  // per-lane mask limits: element (kt, i) of query tile qt is masked iff 16kt + i > lim[qt] (key > query + coff, or key >= Nk)
+  auto apply_mask = [&](f32x4 (&s)[KT][2], const int kv0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      int lim = p.Nk - 1 - kv0 - 4 * g;
+      if (CAUSAL) lim = min(lim, qw0 + 16 * qt + c + coff - kv0 - 4 * g);
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[kt][qt][i] = (16 * kt + i > lim) ? -INFINITY : s[kt][qt][i];
+    }
+  };
+  // S^T = K.Q^T + C : s[kt][qt][i] = S[query 16qt + c][key kv0 + 16kt + 4g + i] + c_[qt]; K fragments read LA ahead of their use
+  auto scores = [&](auto bufc, f32x4 (&s)[KT][2], const f32x4 c0, const f32x4 c1) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    constexpr int NK = KT * KS, LA = FA16_LAK;
+    vec8 kf[NK];
+    auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(kptr[i % KS] + buf * TILE + (i / KS) * 16 * RB)); };
+#pragma unroll
+    for (int i = 0; i < LA; ++i) kread(i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      const int kt = i / KS, ks = i % KS;
+      s[kt][0] = M::mfma(kf[i], qf[0][ks], ks == 0 ? c0 : s[kt][0]);
+      s[kt][1] = M::mfma(kf[i], qf[1][ks], ks == 0 ? c1 : s[kt][1]);
+      if (i + LA < NK) kread(i + LA);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // row maxima of a raw score tile -> new reference: rescale O and l, rewrite m and the C-operand tuples (first tile and rare path)
+  auto new_reference = [&](f32x4 (&s)[KT][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = s[0][qt][0];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][qt][i]);
+      mx = fmaxf(mx, xlane(mx, 16));
+      mx = fmaxf(mx, xlane(mx, 32));
+      const float m_new = fmaxf(m[qt], mx);  // finite: every row sees key 0 of the first tile
+      const float alpha = __builtin_amdgcn_exp2f(m[qt] - m_new);
+      l[qt] *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc[dt][qt][i] *= alpha;
+      m[qt] = m_new;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) negm[qt][i] = -m_new;
+      asm volatile("" : "+v"(negm[qt]));
+    }
+  };
+
+  // One KV tile. FIRST: tile 0 (m = -inf, C operand 0: the scores come out raw), straight-line exact softmax. The others: P =
+  // exp2(S') against the running reference m, where S' comes out of the matrix core with -m already added; the row sums that are
+  // needed anyway tell whether m is stale -- a lane whose 16 probabilities of a row add up to more than 2^THR (or to +inf) has a
+  // score more than 2^THR above m at worst. Only then the wave takes the rare path: raw scores once more, row maxima, rescale
+  // O and l, and the hot path AGAIN from its score product (a backward branch: the score / P registers of the hot path never
+  // merge with anything the rare path computes -- with the rare path as a forward if/else hipcc parked all 32 P values in
+  // scratch on the common path of the non-causal kernel).
+  auto tile = [&](auto bufc, auto firstc, const int t) {
+    constexpr int buf = decltype(bufc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
+    const int kv0 = t * BN;
+    if (t + 1 < nT) stage_dma(t + 1, buf ^ 1);  // the next tile, in flight under this tile's MFMAs
+
+    // whole-tile skip per wave (kernels.metal:682 with Br = 32)
+    // (non-causal: an always-true scalar hipcc cannot see through -- with the tile body unconditional it schedules across the
+    // tile boundary and spills 250-390 B per lane under the 128-register budget; with the branch in place, as in the causal
+    // kernel, it fits)
+    int always = 1;
+    if constexpr (!CAUSAL) asm volatile("" : "+s"(always));
+    const bool wave_active = CAUSAL ? (kv0 <= qw0 + WM - 1 + coff) : (always != 0);
+    if (wave_active) {
+      // mask only on tiles that cross the diagonal or the end of the sequence
+      const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk);
+      f32x4 s[KT][2];
+      float ls[2];
+      if constexpr (FIRST) {
+        scores(bufc, s, negm[0], negm[1]);  // C = 0
+        if (need_mask) apply_mask(s, kv0);
+        new_reference(s);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          ls[qt] = 0.0f;
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              s[kt][qt][i] = __builtin_amdgcn_exp2f(s[kt][qt][i] - m[qt]);
+              ls[qt] += s[kt][qt][i];
+            }
+        }
+      } else {
+        bool retried = false;
+        for (;;) {
+#if FA16_PRIO
+          __builtin_amdgcn_s_setprio(1);
+#endif
+          scores(bufc, s, negm[0], negm[1]);
+          if (need_mask) apply_mask(s, kv0);
+#if FA16_PRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int qt = 0; qt < 2; ++qt) {
+                s[kt][qt][i] = __builtin_amdgcn_exp2f(s[kt][qt][i]);
+                ls[qt] = (kt == 0 && i == 0) ? s[kt][qt][i] : ls[qt] + s[kt][qt][i];
+              }
+          const bool stale = __builtin_amdgcn_ballot_w64(fmaxf(ls[0], ls[1]) > sum_thr) != 0;  // wave-uniform
+          if (__builtin_expect(!stale || retried, 1)) break;
+          f32x4 raw[KT][2], zero;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) zero[i] = 0.0f;
+          scores(bufc, raw, zero, zero);
+          if (need_mask) apply_mask(raw, kv0);
+          new_reference(raw);
+          retried = true;
+        }
+      }
+      l[0] += ls[0];
+      l[1] += ls[1];
+#if FA16_PRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+      // ---- O^T += V^T.P^T : per 32-key step kp the B operand of query tile qt is {s[2kp][qt][0..3], s[2kp+1][qt][0..3]}
+      {
+        constexpr int NV = 2 * DT, LA = FA16_LAV;
+        s16x4 wlo[NV], whi[NV];
+        auto vread = [&](int j) {  // step j = (kp, dt)
+          const lds_char *vb = vptr[j % DT] + buf * TILE + (32 * (j / DT)) * RB;
+          wlo[j] = lds_read_tr16(vb);            // keys 32kp + 4g + 0..3       (k elements 0..3)
+          whi[j] = lds_read_tr16(vb + 16 * RB);  // keys 32kp + 16 + 4g + 0..3  (k elements 4..7)
+        };
+        vec8 pf[2][2];
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[kp][qt][j] = (elem)s[2 * kp + (j >> 2)][qt][j & 3];
+#pragma unroll
+        for (int j = 0; j < LA; ++j) vread(j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const s16x8 v8 = __builtin_shufflevector(wlo[j], whi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) oacc[j % DT][qt] = M::mfma(__builtin_bit_cast(vec8, v8), pf[j / DT][qt], oacc[j % DT][qt]);
+          if (j + LA < NV) vread(j + LA);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#if FA16_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    if (t + 1 < nT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this tile have landed
+    __syncthreads();
+  };
+  tile(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+  for (int t = 1; t < nT; t += 2) {
+    tile(std::integral_constant<int, 1>{}, std::false_type{}, t);
+    if (t + 1 < nT) tile(std::integral_constant<int, 0>{}, std::false_type{}, t + 1);
+  }
+
+  // ---- epilogue: normalise, LSE, O tile -> LDS -> coalesced 16-byte stores
+  lds_char *Ot = smem + wave * (WM * RB);  // this wave's [32][D] tile (inside the K buffers: free since the last barrier)
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float lt = l[qt];
+    lt += xlane(lt, 16);
+    lt += xlane(lt, 32);
+    const float inv_l = 1.0f / lt;
+    const int row = 16 * qt + c, qrow = qw0 + row;
+    if (p.lse != nullptr && g == 0 && qrow < p.N) p.lse[(long long)bh * p.N + qrow] = m[qt] * 0.6931471805599453f + logf(lt);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      // registers 0..3 = d columns 16dt + 4g + 0..3 of row (16qt + c)
+      const elem e0 = (elem)(oacc[dt][qt][0] * inv_l), e1 = (elem)(oacc[dt][qt][1] * inv_l);
+      const elem e2 = (elem)(oacc[dt][qt][2] * inv_l), e3 = (elem)(oacc[dt][qt][3] * inv_l);
+      u32x2 w;
+      w[0] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
+      w[1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+      const int ch = (2 * dt + (g >> 1)) ^ (row & (CPR - 1));  // chunk XOR row spreads the rows over the banks
+      lds_write_b64(Ot + row * RB + (ch << 4) + 8 * (g & 1), w);
+    }
+  }
+  __syncthreads();
+  {
+    elem *Og = (elem *)p.o + base;
+#pragma unroll
+    for (int it = 0; it < WM * CPR / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / CPR, ch = idx % CPR;
+      const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPR - 1))) << 4));
+      if (qw0 + row < p.N) *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
+    }
+  }
+}
+
+template <typename Tag, int D, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA16_OCC : 2)) void fwd_mfma16_kernel(Params p) {
+  fwd_mfma16_body<Tag, D, CAUSAL>(p);
+}
+
+bool mfma16_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D == 64; }
+
+template <typename Tag, int D, bool CAUSAL>
+static hipError_t launch16_one(const Params &p, hipStream_t s) {
+  const int nQ = (p.N + BM - 1) / BM;
+  const size_t smem = 4 * (size_t)BN * D * 2;
+  auto kern = fwd_mfma16_kernel<Tag, D, CAUSAL>;
+  if (smem > 48 * 1024) {
+    hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
+    if (e != hipSuccess) return e;
+  }
+  Params pp = p;
+  pp.head_group = causal_head_group(p, D, 2);
+  set_block_divisors(pp, nQ, pp.head_group);
+  (void)hipGetLastError();  // do not report an older sticky error as this launch's
+  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
+  return hipGetLastError();
+}
+
+hipError_t launch_mfma16(const Params &p, int dtype, hipStream_t s) {
+  if (p.D != 64) return hipErrorInvalidValue;
+  if (dtype == FA_DTYPE_F16) return p.is_causal ? launch16_one<F16, 64, true>(p, s) : launch16_one<F16, 64, false>(p, s);
+  return p.is_causal ? launch16_one<BF16, 64, true>(p, s) : launch16_one<BF16, 64, false>(p, s);
+}
+
+}  // namespace fa

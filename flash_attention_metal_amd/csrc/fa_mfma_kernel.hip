@@ -768,6 +768,9 @@ static hipError_t launch_one_(const Params &p, hipStream_t s) {
 #ifdef FA_DEBUG_KNOBS  // scheduling experiments only: never compiled into the shipped library
   static const int env_head_group = [] { const char *e = getenv("FA_HEAD_GROUP"); return e ? atoi(e) : -1; }();
   if (env_head_group >= 0) pp.head_group = env_head_group;
+#ifdef FA_FORCE_HEAD_GROUP  // compile-time form for tools/ab.py (several builds side by side in one process share the environment)
+  pp.head_group = FA_FORCE_HEAD_GROUP;
+#endif
 #endif
   set_block_divisors(pp, nQ, pp.head_group);
   (void)hipGetLastError();  // do not report an older sticky error as this launch's

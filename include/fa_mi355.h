@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define FA_MI355_VERSION 301 /* major*10000 + minor*100 + patch */
+#define FA_MI355_VERSION 400 /* major*10000 + minor*100 + patch */
 
 /* element type of Q, K, V and O */
 enum fa_dtype {
@@ -64,9 +64,12 @@ enum fa_variant {
   FA_VARIANT_MFMA_EXACT = 8, /* FA_VARIANT_MFMA without the pre-scaled query operand: every score is scaled in fp32 (one more
                             FMA per score, 6-8 % slower at head_dim 64). For logits far larger than a trained model
                             produces; see "LSE accuracy" below. Identical to FA_VARIANT_MFMA for fp8 inputs and D = 256 */
-  FA_VARIANT_MFMA_H64S2 = 9 /* same operator, 64 query rows per workgroup: four waves, the two wave pairs take the even / odd
+  FA_VARIANT_MFMA_H64S2 = 9, /* same operator, 64 query rows per workgroup: four waves, the two wave pairs take the even / odd
                             KV tiles and merge once (twice the workgroups, half the sequential tiles of a block): grids
                             whose critical path is the heaviest causal block (f16 / bf16, head_dim 64) */
+  FA_VARIANT_MFMA16 = 10 /* FA_VARIANT_MFMA's workgroup (128 query rows, pre-scaled query operand) with every product on
+                            v_mfma_f32_16x16x32 instead of 32x32x16: the chip holds a higher clock on that shape under
+                            power-limited loops (f16 / bf16, head_dim 64) */
 };
 
 /* status codes (0 = success, negative = error; text via fa_last_error()) */

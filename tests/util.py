@@ -47,7 +47,7 @@ def is_prescaled(fa, dtype, variant, B, H, N, D, causal=False):
     v = fa.VARIANTS[variant]
     if v == 0:
         v = fa.load_library().fa_resolve_variant_for(fa.DTYPES[dtype], D, B, H, N, int(causal))
-    return v in (fa.VARIANTS["mfma"], fa.VARIANTS["mfma_split2"], fa.VARIANTS["mfma_h64s2"])
+    return v in (fa.VARIANTS["mfma"], fa.VARIANTS["mfma_split2"], fa.VARIANTS["mfma_h64s2"], fa.VARIANTS["mfma16"])
 
 
 def effective_q(oracle, q, dtype, scale=None):

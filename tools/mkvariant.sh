@@ -14,6 +14,7 @@ for f in fa_api fa_scalar_kernels fa_bwd_kernels; do
   [ -f $src/$f.o ] && cp $src/$f.o $out/obj_$name/$f.o
 done
 /opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_mfma_kernel.hip -o $out/obj_$name/fa_mfma_kernel.o &
+/opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_mfma16_kernel.hip -o $out/obj_$name/fa_mfma16_kernel.o &
 /opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_fwd_pp_kernel.hip -o $out/obj_$name/fa_fwd_pp_kernel.o &
 /opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_fwd_splitkv_kernel.hip -o $out/obj_$name/fa_fwd_splitkv_kernel.o &
 wait
