@@ -261,7 +261,9 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
     const int kv0 = t * BT + sub * BN;
     if (kv0 < kv_end && (!CAUSAL || kv0 <= qw0 + WM - 1 + coff)) {
       const int KS = sub * BTILE, VS = 2 * STILE + sub * BTILE;  // K / V sub-tile images, relative to koff / voff
-      const bool need_mask = CAUSAL && (kv0 + BN - 1 > qw0 + coff);
+      // masked: key > query (causal), and -- the partial last tile -- key >= Nk: those K / V rows arrive as zeros through the
+      // descriptor, S' = -lse.log2e there, and with a strongly negative lse P = exp2(S') overflows the cast of dS (inf x 0 = NaN in dQ)
+      const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk);
       // One 32-key half (kb) at a time -- scores, dS, then its share of dQ -- so that only one score and one dP tuple are live
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -300,7 +302,8 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(0);
         if (need_mask) {  // key > query -> masked (kernels.metal:748); a wave-uniform branch
-          const int lim = qrow + coff - kv0 - 32 * kb - 4 * h;
+          int lim = p.Nk - 1 - kv0 - 32 * kb - 4 * h;
+          if (CAUSAL) lim = min(lim, qrow + coff - kv0 - 32 * kb - 4 * h);
 #pragma unroll
           for (int i = 0; i < 16; ++i) sk[i] = ((i & 3) + 8 * (i >> 2) > lim) ? -INFINITY : sk[i];
         }

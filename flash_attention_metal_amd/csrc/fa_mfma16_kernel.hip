@@ -40,6 +40,14 @@
 #ifndef FA16_PRIO
 #define FA16_PRIO 1  // 1: wave priority raised around the MFMA clusters
 #endif
+#ifndef FA16_ONES
+#define FA16_ONES 1  // 1: the row sums come out of the matrix core (a fifth "d tile" of ones in the PV product: +4 MFMAs per 64-key tile) and
+                     // the staleness test reads the exponent bits of the packed probabilities (8 v_or3 instead of 32 v_add): the loop is
+                     // VALU-issue-bound with the matrix pipe half idle, so VALU is traded for MFMA; 0: row sums by v_add, tested against 2^THR
+#endif
+#ifndef FA16_HALVES
+#define FA16_HALVES 0  // 1: the hot pass works on one 32-key half at a time (16 live score registers instead of 32)
+#endif
 #ifndef FA16_OCC
 #define FA16_OCC 4  // workgroups per CU the head_dim-64 kernel is compiled for (128 registers)
 #endif
@@ -164,16 +172,31 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) oacc[dt][qt][i] = 0.0f;
-  float m[2] = {-INFINITY, -INFINITY};  // reference max of row (16qt + c), log2 units (may lag the true max by < 2^THR)
-  float l[2] = {0.0f, 0.0f};            // this lane's share of the row sums
+  constexpr bool ONES = (FA16_ONES != 0);
+  // ONES: probabilities are formed against a reference BIAS log2 units ABOVE the row maximum found when the reference was last set
+  // (P' = P / 2^BIAS <= 2^-BIAS then), so that "some score has since risen THR = BIAS + 1 above that maximum" reads "some P' >= 2",
+  // i.e. "the top exponent bit of some packed P' is set" -- an OR over the 16 packed registers instead of 32 additions. bf16 keeps
+  // fp32's exponent range (BIAS 7: THR 8 as before); f16 loses probabilities below 2^-24, so its reference sits only 3 above (THR 4).
+  constexpr float BIAS = !ONES ? 0.0f : std::is_same<Tag, F16>::value ? 3.0f : 7.0f;
+  // (the reference of row (16qt + c) itself -- log2 units: a stale row max + BIAS -- lives negated in negm[qt] below)
+  float l[2] = {0.0f, 0.0f};            // !ONES: this lane's share of the row sums
+  f32x4 lacc[2];                        // ONES: the row sums, complete, in every register of the tuple (accumulator of the ones tile)
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lacc[qt][i] = 0.0f;
+  vec8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (elem)1.0f;
+  if constexpr (ONES) asm volatile("" : "+v"(ones));
   const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
-  // -m in the 4 registers of a tuple per query tile = the C operand of each score chain's first MFMA (0 until the first
-  // tile has set m: the first tile's scores come out raw and go through the exact path)
+  // minus the reference in the 4 registers of a tuple per query tile = the C operand of each score chain's first MFMA (+inf, i.e.
+  // reference -inf, until the first tile's rare path has set it)
   f32x4 negm[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) negm[qt][i] = 0.0f;
+    for (int i = 0; i < 4; ++i) negm[qt][i] = INFINITY;
     asm volatile("" : "+v"(negm[qt]));  // opaque: else hipcc re-materialises the splat in front of every MFMA
   }
 
@@ -191,68 +214,135 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   __syncthreads();
 
   const float sum_thr = __builtin_exp2f(FA16_DEFER_THR);
-  // per-lane mask limits: element (kt, i) of query tile qt is masked iff 16kt + i > lim[qt] (key > query + coff, or key >= Nk)
-  auto apply_mask = [&](f32x4 (&s)[KT][2], const int kv0) __attribute__((always_inline)) {
+  // element (kt, i) of query tile qt is masked iff 16kt + i > lim[qt] (key > query + coff, or key >= Nk); NKT key tiles from tile K0 on
+  auto apply_mask = [&](auto k0c, auto &s, const int kv0) __attribute__((always_inline)) {
+    constexpr int K0 = decltype(k0c)::value;
+    constexpr int NKT = sizeof(s) / sizeof(s[0]);
+    int g4 = 4 * g;
+    asm volatile("" : "+v"(g4));  // pins the limits and the 32 compares inside the caller's `if (need_mask)`: hipcc otherwise hoists them in front of EVERY tile
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      int lim = p.Nk - 1 - kv0 - 4 * g;
-      if (CAUSAL) lim = min(lim, qw0 + 16 * qt + c + coff - kv0 - 4 * g);
+      int lim = p.Nk - 1 - kv0 - g4;
+      if (CAUSAL) lim = min(lim, qw0 + 16 * qt + c + coff - kv0 - g4);
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+      for (int k2 = 0; k2 < NKT; ++k2)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[kt][qt][i] = (16 * kt + i > lim) ? -INFINITY : s[kt][qt][i];
+        for (int i = 0; i < 4; ++i) s[k2][qt][i] = (16 * (K0 + k2) + i > lim) ? -INFINITY : s[k2][qt][i];
     }
   };
-  // S^T = K.Q^T + C : s[kt][qt][i] = S[query 16qt + c][key kv0 + 16kt + 4g + i] + c_[qt]; K fragments read LA ahead of their use
-  auto scores = [&](auto bufc, f32x4 (&s)[KT][2], const f32x4 c0, const f32x4 c1) __attribute__((always_inline)) {
+  // mask only on tiles that cross the diagonal or the end of the sequence (re-evaluated from scalars at every use: carried as a
+  // bool across the passes of a tile hipcc kept it in a VGPR, v_cndmask + v_cmp per tile)
+  auto needs_mask = [&](const int kv0) __attribute__((always_inline)) { return (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk); };
+  // S^T = K.Q^T + C for NKT key tiles from tile K0 on: s[k2][qt][i] = S[query 16qt + c][key kv0 + 16(K0 + k2) + 4g + i] + c_[qt];
+  // K fragments read LA ahead of their use
+  auto score_group = [&](auto bufc, auto k0c, auto &s, const f32x4 c0, const f32x4 c1) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value;
-    constexpr int NK = KT * KS, LA = FA16_LAK;
+    constexpr int K0 = decltype(k0c)::value;
+    constexpr int NKT = sizeof(s) / sizeof(s[0]);
+    constexpr int NK = NKT * KS, LA = (FA16_LAK < NK) ? FA16_LAK : NK;
     vec8 kf[NK];
-    auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(kptr[i % KS] + buf * TILE + (i / KS) * 16 * RB)); };
+    auto kread = [&](int i) { kf[i] = __builtin_bit_cast(vec8, lds_read_b128(kptr[i % KS] + buf * TILE + (K0 + i / KS) * 16 * RB)); };
 #pragma unroll
     for (int i = 0; i < LA; ++i) kread(i);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
-      const int kt = i / KS, ks = i % KS;
-      s[kt][0] = M::mfma(kf[i], qf[0][ks], ks == 0 ? c0 : s[kt][0]);
-      s[kt][1] = M::mfma(kf[i], qf[1][ks], ks == 0 ? c1 : s[kt][1]);
+      const int k2 = i / KS, ks = i % KS;
+      s[k2][0] = M::mfma(kf[i], qf[0][ks], ks == 0 ? c0 : s[k2][0]);
+      s[k2][1] = M::mfma(kf[i], qf[1][ks], ks == 0 ? c1 : s[k2][1]);
       if (i + LA < NK) kread(i + LA);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  // row maxima of a raw score tile -> new reference: rescale O and l, rewrite m and the C-operand tuples (first tile and rare path)
-  auto new_reference = [&](f32x4 (&s)[KT][2]) __attribute__((always_inline)) {
+  // pack the probabilities of NKT key tiles (from K0 on) into the PV operands pf[kp][qt] (k-step kp = two key tiles), rounded to
+  // the input type; ONES: OR the packed words into `bits`
+  auto pack_group = [&](auto k0c, auto &s, vec8 (&pf)[2][2], unsigned &bits) __attribute__((always_inline)) {
+    constexpr int K0 = decltype(k0c)::value;
+    constexpr int NKT = sizeof(s) / sizeof(s[0]);
+#pragma unroll
+    for (int kp = 0; kp < NKT / 2; ++kp)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[K0 / 2 + kp][qt][j] = (elem)s[2 * kp + (j >> 2)][qt][j & 3];
+        if constexpr (ONES) {
+          const u32x4 w = __builtin_bit_cast(u32x4, pf[K0 / 2 + kp][qt]);
+          bits |= w[0] | w[1] | w[2] | w[3];
+        }
+      }
+  };
+  // the hot pass over NKT key tiles: P = exp2(S') -> pf (and `bits`, or the row sums ls)
+  auto hot_group = [&](auto bufc, auto k0c, auto nktc, const int kv0, vec8 (&pf)[2][2], unsigned &bits,
+                       float (&ls)[2]) __attribute__((always_inline)) {
+    constexpr int NKT = decltype(nktc)::value;
+    f32x4 s[NKT][2];
+    score_group(bufc, k0c, s, negm[0], negm[1]);
+    if (needs_mask(kv0)) apply_mask(k0c, s, kv0);
+#if FA16_PRIO
+    if constexpr (decltype(k0c)::value + NKT == KT) __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+    for (int k2 = 0; k2 < NKT; ++k2)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          s[k2][qt][i] = __builtin_amdgcn_exp2f(s[k2][qt][i]);
+          if constexpr (!ONES) ls[qt] = (decltype(k0c)::value == 0 && k2 == 0 && i == 0) ? s[k2][qt][i] : ls[qt] + s[k2][qt][i];
+        }
+    pack_group(k0c, s, pf, bits);
+  };
+  // the row maxima of the raw scores of NKT key tiles, into mx[qt] (this lane's keys)
+  auto max_group = [&](auto bufc, auto k0c, auto nktc, const int kv0, float (&mx)[2]) __attribute__((always_inline)) {
+    constexpr int NKT = decltype(nktc)::value;
+    f32x4 s[NKT][2], zero;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zero[i] = 0.0f;
+    score_group(bufc, k0c, s, zero, zero);
+    if (needs_mask(kv0)) apply_mask(k0c, s, kv0);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int k2 = 0; k2 < NKT; ++k2)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mx[qt] = fmaxf(mx[qt], s[k2][qt][i]);
+  };
+  // row maxima of the raw scores -> new reference: rescale O and the row sums, rewrite the C-operand tuples (first tile and rare path)
+  auto new_reference = [&](float (&mx)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float mx = s[0][qt][0];
+      float v = mx[qt];
+      v = fmaxf(v, xlane(v, 16));
+      v = fmaxf(v, xlane(v, 32));
+      const float m_old = -negm[qt][0];
+      const float m_new = fmaxf(m_old, v + BIAS);  // finite: every row sees key 0 of the first tile
+      const float alpha = __builtin_amdgcn_exp2f(m_old - m_new);
+      if constexpr (ONES) {
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mx = fmaxf(mx, s[kt][qt][i]);
-      mx = fmaxf(mx, xlane(mx, 16));
-      mx = fmaxf(mx, xlane(mx, 32));
-      const float m_new = fmaxf(m[qt], mx);  // finite: every row sees key 0 of the first tile
-      const float alpha = __builtin_amdgcn_exp2f(m[qt] - m_new);
-      l[qt] *= alpha;
+        for (int i = 0; i < 4; ++i) lacc[qt][i] *= alpha;
+      } else {
+        l[qt] *= alpha;
+      }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[dt][qt][i] *= alpha;
-      m[qt] = m_new;
 #pragma unroll
       for (int i = 0; i < 4; ++i) negm[qt][i] = -m_new;
       asm volatile("" : "+v"(negm[qt]));
     }
   };
+  constexpr int G = (FA16_HALVES != 0) ? 2 : 1;  // key-tile groups of the hot pass: 1 = all 16 score MFMAs, then the softmax; 2 = per 32-key half
+  using KTG = std::integral_constant<int, KT / G>;
+  using K0A = std::integral_constant<int, 0>;
+  using K0B = std::integral_constant<int, KT / 2>;
 
-  // One KV tile. FIRST: tile 0 (m = -inf, C operand 0: the scores come out raw), straight-line exact softmax. The others: P =
-  // exp2(S') against the running reference m, where S' comes out of the matrix core with -m already added; the row sums that are
-  // needed anyway tell whether m is stale -- a lane whose 16 probabilities of a row add up to more than 2^THR (or to +inf) has a
-  // score more than 2^THR above m at worst. Only then the wave takes the rare path: raw scores once more, row maxima, rescale
-  // O and l, and the hot path AGAIN from its score product (a backward branch: the score / P registers of the hot path never
-  // merge with anything the rare path computes -- with the rare path as a forward if/else hipcc parked all 32 P values in
-  // scratch on the common path of the non-causal kernel).
+  // One KV tile: P = exp2(S') against the running reference (S' comes out of the matrix core with the reference already subtracted), and
+  // a test whether the reference is stale -- ONES: some packed P' has its top exponent bit set (P' >= 2, inf or NaN); else: a lane's 16
+  // probabilities of a row add up to more than 2^THR. Only then -- and on the first tile, whose reference is -inf -- the wave takes the
+  // rare path: one pass for the row maxima of the raw scores, rescale O and the row sums, and the hot pass AGAIN (a backward branch:
+  // the score / P registers of the hot pass never merge with anything the rare path computes -- with the rare path as a forward
+  // if / else hipcc parked all 32 P values in scratch on the common path of the non-causal kernel).
   auto tile = [&](auto bufc, auto firstc, const int t) {
     constexpr int buf = decltype(bufc)::value;
     constexpr bool FIRST = decltype(firstc)::value;
@@ -267,62 +357,36 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
     if constexpr (!CAUSAL) asm volatile("" : "+s"(always));
     const bool wave_active = CAUSAL ? (kv0 <= qw0 + WM - 1 + coff) : (always != 0);
     if (wave_active) {
-      // mask only on tiles that cross the diagonal or the end of the sequence
-      const bool need_mask = (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk);
-      f32x4 s[KT][2];
-      float ls[2];
-      if constexpr (FIRST) {
-        scores(bufc, s, negm[0], negm[1]);  // C = 0
-        if (need_mask) apply_mask(s, kv0);
-        new_reference(s);
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          ls[qt] = 0.0f;
-#pragma unroll
-          for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              s[kt][qt][i] = __builtin_amdgcn_exp2f(s[kt][qt][i] - m[qt]);
-              ls[qt] += s[kt][qt][i];
-            }
+      vec8 pf[2][2];  // B operands of the PV product: k-step kp, query tile qt
+      float ls[2] = {0.0f, 0.0f};
+      bool redo = FIRST;  // wave-uniform
+      for (;;) {
+        if (__builtin_expect(redo, 0)) {
+          float mx[2] = {-INFINITY, -INFINITY};
+          max_group(bufc, K0A{}, std::integral_constant<int, KT / 2>{}, kv0, mx);
+          max_group(bufc, K0B{}, std::integral_constant<int, KT / 2>{}, kv0, mx);
+          new_reference(mx);
         }
-      } else {
-        bool retried = false;
-        for (;;) {
 #if FA16_PRIO
-          __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #endif
-          scores(bufc, s, negm[0], negm[1]);
-          if (need_mask) apply_mask(s, kv0);
-#if FA16_PRIO
-          __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll
-          for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int qt = 0; qt < 2; ++qt) {
-                s[kt][qt][i] = __builtin_amdgcn_exp2f(s[kt][qt][i]);
-                ls[qt] = (kt == 0 && i == 0) ? s[kt][qt][i] : ls[qt] + s[kt][qt][i];
-              }
-          const bool stale = __builtin_amdgcn_ballot_w64(fmaxf(ls[0], ls[1]) > sum_thr) != 0;  // wave-uniform
-          if (__builtin_expect(!stale || retried, 1)) break;
-          f32x4 raw[KT][2], zero;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) zero[i] = 0.0f;
-          scores(bufc, raw, zero, zero);
-          if (need_mask) apply_mask(raw, kv0);
-          new_reference(raw);
-          retried = true;
-        }
+        unsigned bits = 0;
+        hot_group(bufc, K0A{}, KTG{}, kv0, pf, bits, ls);
+        if constexpr (G == 2) hot_group(bufc, K0B{}, KTG{}, kv0, pf, bits, ls);
+        bool stale;
+        if constexpr (ONES) stale = __builtin_amdgcn_ballot_w64((bits & 0x40004000u) != 0) != 0;
+        else stale = __builtin_amdgcn_ballot_w64(fmaxf(ls[0], ls[1]) > sum_thr) != 0;
+        if (__builtin_expect(!stale || redo, 1)) break;  // (after a redo every P' <= 2^-BIAS: a second stale reading is inf / NaN input)
+        redo = true;
       }
-      l[0] += ls[0];
-      l[1] += ls[1];
+      if constexpr (!ONES) {
+        l[0] += ls[0];
+        l[1] += ls[1];
+      }
 #if FA16_PRIO
       __builtin_amdgcn_s_setprio(1);
 #endif
-      // ---- O^T += V^T.P^T : per 32-key step kp the B operand of query tile qt is {s[2kp][qt][0..3], s[2kp+1][qt][0..3]}
+      // ---- O^T += V^T.P^T, and (ONES) the row sums from a fifth d tile of ones
       {
         constexpr int NV = 2 * DT, LA = FA16_LAV;
         s16x4 wlo[NV], whi[NV];
@@ -331,13 +395,6 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
           wlo[j] = lds_read_tr16(vb);            // keys 32kp + 4g + 0..3       (k elements 0..3)
           whi[j] = lds_read_tr16(vb + 16 * RB);  // keys 32kp + 16 + 4g + 0..3  (k elements 4..7)
         };
-        vec8 pf[2][2];
-#pragma unroll
-        for (int kp = 0; kp < 2; ++kp)
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[kp][qt][j] = (elem)s[2 * kp + (j >> 2)][qt][j & 3];
 #pragma unroll
         for (int j = 0; j < LA; ++j) vread(j);
         __builtin_amdgcn_sched_barrier(0);
@@ -347,6 +404,12 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) oacc[j % DT][qt] = M::mfma(__builtin_bit_cast(vec8, v8), pf[j / DT][qt], oacc[j % DT][qt]);
           if (j + LA < NV) vread(j + LA);
+          if constexpr (ONES) {
+            if (j % DT == DT - 1) {
+#pragma unroll
+              for (int qt = 0; qt < 2; ++qt) lacc[qt] = M::mfma(ones, pf[j / DT][qt], lacc[qt]);
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -367,20 +430,24 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   lds_char *Ot = smem + wave * (WM * RB);  // this wave's [32][D] tile (inside the K buffers: free since the last barrier)
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    float lt = l[qt];
-    lt += xlane(lt, 16);
-    lt += xlane(lt, 32);
-    const float inv_l = 1.0f / lt;
+    float lt = ONES ? lacc[qt][0] : l[qt];
+    if constexpr (!ONES) {
+      lt += xlane(lt, 16);
+      lt += xlane(lt, 32);
+    }
+    const float inv_l = __builtin_amdgcn_rcpf(lt);  // v_rcp_f32 (1 ulp): the IEEE division costs ten instructions per row
     const int row = 16 * qt + c, qrow = qw0 + row;
-    if (p.lse != nullptr && g == 0 && qrow < p.N) p.lse[(long long)bh * p.N + qrow] = m[qt] * 0.6931471805599453f + logf(lt);
+    // LSE = (reference + log2 l) . ln 2, v_log_f32 straight (l is a sum of probabilities around 2^-BIAS .. 2^THR: no denormals)
+    if (p.lse != nullptr && g == 0 && qrow < p.N)
+      p.lse[(long long)bh * p.N + qrow] = (__builtin_amdgcn_logf(lt) - negm[qt][0]) * 0.6931471805599453f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      // registers 0..3 = d columns 16dt + 4g + 0..3 of row (16qt + c)
-      const elem e0 = (elem)(oacc[dt][qt][0] * inv_l), e1 = (elem)(oacc[dt][qt][1] * inv_l);
-      const elem e2 = (elem)(oacc[dt][qt][2] * inv_l), e3 = (elem)(oacc[dt][qt][3] * inv_l);
-      u32x2 w;
-      w[0] = (unsigned)__builtin_bit_cast(unsigned short, e0) | ((unsigned)__builtin_bit_cast(unsigned short, e1) << 16);
-      w[1] = (unsigned)__builtin_bit_cast(unsigned short, e2) | ((unsigned)__builtin_bit_cast(unsigned short, e3) << 16);
+      // registers 0..3 = d columns 16dt + 4g + 0..3 of row (16qt + c); converted as one vector so that hipcc packs pairs
+      typedef elem elem4 __attribute__((ext_vector_type(4)));
+      elem4 e;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e[i] = (elem)(oacc[dt][qt][i] * inv_l);
+      const u32x2 w = __builtin_bit_cast(u32x2, e);
       const int ch = (2 * dt + (g >> 1)) ^ (row & (CPR - 1));  // chunk XOR row spreads the rows over the banks
       lds_write_b64(Ot + row * RB + (ch << 4) + 8 * (g & 1), w);
     }

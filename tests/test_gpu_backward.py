@@ -153,6 +153,35 @@ def test_backward_rectangular(fa, oracle_mod, causal, D):
         assert e.value.status == -2
 
 
+@pytest.mark.parametrize("D", [64, 128])
+def test_backward_partial_last_key_tile_with_strongly_negative_scores(fa, oracle_mod, D):
+    """Non-causal, Nk % 64 != 0, every score strongly negative (k = -8 q direction, f16): lse << 0, so a key slot past Nk -- whose
+    K / V rows arrive as zeros -- would give P = exp(-lse) and overflow the cast of dS (inf x 0 = NaN in the whole dQ row) unless the
+    dQ kernel masks keys >= Nk in the partial last tile as the forward does."""
+    import torch
+
+    dtype = "f16"
+    for (B, Hq, Hkv, Nq, Nk) in ((1, 2, 2, 96, 77), (1, 2, 1, 130, 129), (1, 1, 1, 64, 260)):
+        rng = np.random.default_rng(Nk)
+        u = rng.standard_normal((B, Hkv, 1, D)).astype(np.float32)
+        u /= np.sqrt((u ** 2).sum(-1, keepdims=True))
+        q = oracle_mod.round_to(np.repeat(u, Hq // Hkv, axis=1) * 5.0 + 0.05 * rng.standard_normal((B, Hq, Nq, D)).astype(np.float32), dtype)
+        k = oracle_mod.round_to(-8.0 * u * 5.0 + 0.05 * rng.standard_normal((B, Hkv, Nk, D)).astype(np.float32), dtype)
+        v = oracle_mod.round_to(rng.uniform(-1, 1, (B, Hkv, Nk, D)).astype(np.float32), dtype)
+        do = oracle_mod.round_to(rng.uniform(-1, 1, (B, Hq, Nq, D)).astype(np.float32), dtype)
+        qd, kd, vd, dod = (to_dev(x, dtype) for x in (q, k, v, do))
+        o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=False)
+        assert lse.max().item() < -12.0  # the regime the advisory describes: exp(-lse) is beyond the f16 range
+        dq, dk, dv = fa.flash_attention_backward(qd, kd, vd, o, dod, lse, is_causal=False)
+        torch.cuda.synchronize()
+        for name, g, ref in zip(("dq", "dk", "dv"), (dq, dk, dv), rect_reference(q, k, v, do, False)):
+            g = g.cpu().numpy()
+            assert np.isfinite(g).all(), (name, Nq, Nk, D)
+            # (logits around -25: the rounding of the pre-scaled operands moves every score by ~1e-2, section "LSE accuracy" of the header;
+            # the point here is a finite, sane gradient -- before the fix the whole dQ row was NaN)
+            assert rel(g, ref) < 0.1, (name, Nq, Nk, D, rel(g, ref))
+
+
 def test_backward_known_answers(fa, oracle_mod):
     import torch
 

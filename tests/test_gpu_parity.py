@@ -17,7 +17,7 @@ Index logic (causal mask, tile skip, head/batch addressing) is checked bit-exact
 import numpy as np
 import pytest
 
-from util import LN2, effective_q, is_prescaled, lse_tol, make_qkv, o_tol, run_op, to_dev
+from util import LN2, effective_q, is_prescaled, lse_tol, make_qkv, o_tol, rowsum_term, run_op, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -51,7 +51,7 @@ def check(fa, oracle, q, k, v, dtype, causal, variant, tol_scale=1.0, scale=None
         o64, lse64 = oracle.attn_fwd_f64(effective_q(oracle, q, dtype, scale), k, v, causal, LN2)
         err_o, err_l = np.abs(o - o64).max(), np.abs(lse - lse64).max()
         assert err_o < TOL_O[dtype] * tol_scale, (variant, dtype, causal, q.shape, err_o, "vs oracle on Q~")
-        assert err_l < TOL_LSE[dtype] * tol_scale, (variant, dtype, causal, q.shape, err_l, "vs oracle on Q~")
+        assert err_l < TOL_LSE[dtype] * tol_scale + rowsum_term(dtype, pre), (variant, dtype, causal, q.shape, err_l, "vs oracle on Q~")
     # against the true Q: the plain tolerances, plus the documented operand-rounding bound where it applies
     o64, lse64 = oracle.attn_fwd_f64(q, k, v, causal, scale)
     err_o = np.abs(o - o64).max()
@@ -329,7 +329,7 @@ def test_randomized_shapes(fa, oracle_mod, variant):
         assert np.abs(lse - l64).max() < lse_tol(dtype, pre, q, k, scale), (B, H, N, D, dtype, causal, scale)
         if pre:
             o64, l64 = oracle_mod.attn_fwd_f64(effective_q(oracle_mod, q, dtype, scale), k, v, causal, LN2)
-            assert np.abs(o - o64).max() < tol and np.abs(lse - l64).max() < 1e-4, (B, H, N, D, dtype, causal, scale)
+            assert np.abs(o - o64).max() < tol and np.abs(lse - l64).max() < 1e-4 + rowsum_term(dtype, pre), (B, H, N, D, dtype, causal, scale)
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
@@ -614,7 +614,7 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, varia
         if pre:  # strict vs the oracle on the operand the kernel multiplies
             o64, l64 = oracle_mod.attn_rows_f64(effective_q(oracle_mod, qh, dtype), kh, vh, rows, causal, LN2)
             assert np.abs(o[b, h].float().cpu().numpy()[rows] - o64).max() < TOL_O[dtype]
-            assert np.abs(lse[b, h].cpu().numpy()[rows] - l64).max() < TOL_LSE[dtype]
+            assert np.abs(lse[b, h].cpu().numpy()[rows] - l64).max() < TOL_LSE[dtype] + rowsum_term(dtype, pre)
     assert worst_o < TOL_O[dtype] and worst_l < tol_l, (worst_o, worst_l)
     # V = const -> O = const (the softmax weights sum to 1), any size
     ones = torch.full_like(v, 0.5)

@@ -47,7 +47,20 @@ def is_prescaled(fa, dtype, variant, B, H, N, D, causal=False):
     v = fa.VARIANTS[variant]
     if v == 0:
         v = fa.load_library().fa_resolve_variant_for(fa.DTYPES[dtype], D, B, H, N, int(causal))
-    return v in (fa.VARIANTS["mfma"], fa.VARIANTS["mfma_split2"], fa.VARIANTS["mfma_h64s2"], fa.VARIANTS["mfma16"])
+    if v == fa.VARIANTS["mfma16"]:
+        return 2  # pre-scaled operand AND row sums over the ROUNDED probabilities (rowsum_term below)
+    return int(v in (fa.VARIANTS["mfma"], fa.VARIANTS["mfma_split2"], fa.VARIANTS["mfma_h64s2"]))
+
+
+# The 16x16x32 kernel (csrc/fa_mfma16_kernel.hip) takes its row sums from the matrix core: l = sum of the probabilities AFTER their
+# rounding to the input type (the same values the PV product multiplies, so O's weights add up to exactly 1), where the other kernels
+# add the fp32 probabilities. ln(l) therefore carries the rounding of P: at most half an ulp of the input type, relative (every P moves
+# by a factor within 1 +- eps), far less on average (the roundings of a row's many P values are independent). include/fa_mi355.h, "LSE accuracy".
+ROWSUM_EPS = {"f16": 2.0 ** -11, "bf16": 2.0 ** -8}
+
+
+def rowsum_term(dtype, prescaled):
+    return ROWSUM_EPS.get(dtype, 0.0) if prescaled == 2 else 0.0
 
 
 def effective_q(oracle, q, dtype, scale=None):
@@ -69,7 +82,7 @@ def prescale_delta(dtype, q, k, scale=None):
 def lse_tol(dtype, prescaled, q, k, scale=None, base=1e-4):
     """LSE tolerance against the oracle on the TRUE Q: `base` (fp32 accumulation) plus, for the pre-scaled kernels, the bound
     the header states (LSE moves by at most the largest score perturbation)."""
-    return base + (prescale_delta(dtype, q, k, scale) if prescaled and dtype in PRESCALE_EPS else 0.0)
+    return base + rowsum_term(dtype, prescaled) + (prescale_delta(dtype, q, k, scale) if prescaled and dtype in PRESCALE_EPS else 0.0)
 
 
 def o_tol(dtype, prescaled, q, k, v, scale=None, base=0.0):
