@@ -15,6 +15,7 @@ SYMBOLS = {
     "fa_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                        c_float, c_longlong, c_longlong, c_int, c_int, c_int, c_void_p]),
     "fa_fwd_ex": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_longlong] * 4 + [c_int, c_int, c_void_p]),
+    "fa_fwd_exv": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_longlong] * 4 + [c_int, c_int, c_int, c_void_p]),
     "fa_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_longlong, c_longlong, c_int, c_int, c_void_p]),
     "fa_bwd_ex": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float] + [c_longlong] * 4 + [c_int, c_int, c_void_p]),
     "fa_bwd_workspace_bytes": (c_longlong, [c_int, c_int, c_int]),

@@ -111,6 +111,10 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   // (fp8 inputs at head_dim 64 already from N = 1024: 64 heads x 1024, 16.7 -> 14.7 us)
   const int n_min = (dtype == FA_DTYPE_FP8_E4M3 && D == 64) ? 1024 : 2048;
   if (fa::mfma_split2_supported(dtype, D) && is_causal && N >= n_min && blocks128 <= 512) return FA_VARIANT_MFMA_SPLIT2;
+  // head_dim 64, 16-bit inputs, grids that fill the chip: the same workgroup on the 16x16x32 instruction with its row sums on the matrix
+  // core -- config 3 +2 %, N >= 4096 non-causal / N >= 8192 causal +4.5..5.7 %; level at N = 2048, 1-2 % behind at N = 1024 (its
+  // first tile pays a second score pass) (profiles/r04/ab_mfma16_ones_vs_adds.log)
+  if (fa::mfma16_supported(dtype, D) && N >= 2048) return FA_VARIANT_MFMA16;
   return FA_VARIANT_MFMA;
 }
 
@@ -129,6 +133,7 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
       snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s, %s>", tag, D, c,
                (dtype != FA_DTYPE_FP8_E4M3 && D <= 128) ? "true" : "false");  // pre-scaled operand where it exists
       break;
+    case FA_VARIANT_MFMA_EXACT: snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s, false>", tag, D, c); break;
     case FA_VARIANT_TILED_V2: snprintf(name, sizeof(name), "fa::tiled_v2_kernel"); break;
     default: name[0] = 0;
   }
@@ -209,6 +214,13 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
 int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse, int B, int Hq, int Hkv, int Nq, int Nk,
               int D, float scale, long long q_batch_stride, long long q_head_stride, long long kv_batch_stride,
               long long kv_head_stride, int is_causal, int dtype, void *hip_stream) {
+  return fa_fwd_exv(q, k, v, o, lse, B, Hq, Hkv, Nq, Nk, D, scale, q_batch_stride, q_head_stride, kv_batch_stride, kv_head_stride,
+                    is_causal, dtype, FA_VARIANT_AUTO, hip_stream);
+}
+
+int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse, int B, int Hq, int Hkv, int Nq, int Nk,
+               int D, float scale, long long q_batch_stride, long long q_head_stride, long long kv_batch_stride,
+               long long kv_head_stride, int is_causal, int dtype, int variant, void *hip_stream) {
   g_err[0] = 0;
   if (!q || !k || !v || !o) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: null tensor pointer");
   if (B < 1 || Hq < 1 || Hkv < 1 || Nq < 1 || Nk < 1 || D < 1)
@@ -227,7 +239,8 @@ int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse, 
     return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: bad strides");
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15)
     return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: tensors must be 16-byte aligned");
-  if ((double)std::max(Nq, Nk) * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)
+  // (as in fa_fwd: the staging loops may address up to two 64-key tiles past the end of a head)
+  if ((double)(std::max(Nq, Nk) + 128) * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)
     return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: one head exceeds 4 GiB");
   if (q_batch_stride < 0 || kv_batch_stride < 0) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: negative batch stride");
   if ((long long)B * Hq > 0x7fffffffLL / ((Nq + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: grid too large");
@@ -242,8 +255,24 @@ int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse, 
   // head_dim 64 only: there it is 1.2-3x faster than the 128-row kernel at every key length (32 heads x 1 query x 16384 keys:
   // 165 -> 55 us), at head_dim 128 its four private 32-KiB tiles make it 2-4x SLOWER (profiles/r03/decode_steps_splitkv_rule.log)
   const long long blocks128 = (long long)B * Hq * ((Nq + 127) / 128);
-  const bool small_grid = D == 64 && fa::splitkv_supported(dtype, D) && Nk > 64 && blocks128 <= 64;
-  hipError_t e = small_grid ? fa::launch_splitkv(p, dtype, (hipStream_t)hip_stream) : fa::launch_mfma(p, dtype, (hipStream_t)hip_stream);
+  if (variant == FA_VARIANT_AUTO) {
+    const bool small_grid = D == 64 && fa::splitkv_supported(dtype, D) && Nk > 64 && blocks128 <= 64;
+    // the 16x16x32 kernel where fa_fwd's AUTO takes it: head_dim 64, 16-bit inputs, long key sequences on a grid that fills the chip
+    variant = small_grid ? FA_VARIANT_MFMA_SPLITKV
+              : (fa::mfma16_supported(dtype, D) && Nk >= 2048 && blocks128 > 512) ? FA_VARIANT_MFMA16 : FA_VARIANT_MFMA;
+  }
+  // the kernels that take the generalised problem (key/value heads, Nk): the 128-row kernel with / without its pre-scaled operand, its
+  // 16x16x32 form, the split-KV kernel
+  if (variant != FA_VARIANT_MFMA && variant != FA_VARIANT_MFMA_EXACT && variant != FA_VARIANT_MFMA16 && variant != FA_VARIANT_MFMA_SPLITKV)
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: variant=%s does not take grouped heads / Nq != Nk (mfma, mfma_exact, mfma16, mfma_splitkv do)",
+                fa_variant_name(variant));
+  if (!fa_supported(dtype, variant, D))
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: variant=%s does not support dtype=%s D=%d", fa_variant_name(variant), fa_dtype_name(dtype), D);
+  p.exact = (variant == FA_VARIANT_MFMA_EXACT);
+  hipStream_t s = (hipStream_t)hip_stream;
+  const hipError_t e = variant == FA_VARIANT_MFMA_SPLITKV ? fa::launch_splitkv(p, dtype, s)
+                       : variant == FA_VARIANT_MFMA16     ? fa::launch_mfma16(p, dtype, s)
+                                                          : fa::launch_mfma(p, dtype, s);
   if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_fwd_ex: launch failed: %s", hipGetErrorString(e));
   return FA_OK;
 }

@@ -359,7 +359,8 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
     if (wave_active) {
       vec8 pf[2][2];  // B operands of the PV product: k-step kp, query tile qt
       float ls[2] = {0.0f, 0.0f};
-      bool redo = FIRST;  // wave-uniform
+      bool redo = FIRST;  // wave-uniform: first the row maxima of the raw scores -> new reference (first tile: the reference is -inf;
+                          // a 16-key reference for it, 4 MFMAs instead of 16, was measured: no gain, profiles/r04/ab_mfma16_first_tile.log)
       for (;;) {
         if (__builtin_expect(redo, 0)) {
           float mx[2] = {-INFINITY, -INFINITY};

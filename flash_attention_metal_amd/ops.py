@@ -117,7 +117,7 @@ def flash_attention_forward(
     """Launch the gfx950 kernel on the current torch stream (asynchronous)."""
     lib = load_library()
     if q.dim() == 4 and k.dim() == 4 and k.shape == v.shape and q.shape != k.shape:
-        return _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream)  # GQA / Nq != Nk
+        return _forward_ex(lib, q, k, v, is_causal, scale, variant, return_lse, out, lse, stream)  # GQA / Nq != Nk
     args, out, lse = _prepare_forward(q, k, v, is_causal, scale, variant, return_lse, out, lse)
     _launch_forward(lib, args, q.device, stream)
     return out, lse
@@ -141,9 +141,10 @@ class ForwardPlan:
         _launch_forward(self._lib, self._args, self._device, stream)
 
 
-def _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream):
-    """Generalised call (include/fa_mi355.h fa_fwd_ex): q [B,Hq,Nq,D], k/v [B,Hkv,Nk,D], Hq % Hkv == 0,
-    causal bottom-right aligned (key j visible to query i iff j <= i + Nk - Nq)."""
+def _forward_ex(lib, q, k, v, is_causal, scale, variant, return_lse, out, lse, stream):
+    """Generalised call (include/fa_mi355.h fa_fwd_exv): q [B,Hq,Nq,D], k/v [B,Hkv,Nk,D], Hq % Hkv == 0,
+    causal bottom-right aligned (key j visible to query i iff j <= i + Nk - Nq). `variant`: auto, mfma, mfma_exact, mfma16 or
+    mfma_splitkv -- the kernels that take grouped heads / Nq != Nk; any other raises FaError (unsupported), never a silent substitute."""
     B, Hq, Nq, D = q.shape
     Bk, Hkv, Nk, Dk = k.shape
     if Bk != B or Dk != D or Hq % Hkv:
@@ -174,8 +175,8 @@ def _forward_ex(lib, q, k, v, is_causal, scale, return_lse, out, lse, stream):
     if stream is None:
         stream = torch.cuda.current_stream(q.device).cuda_stream
     with torch.cuda.device(q.device):
-        st = lib.fa_fwd_ex(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
-                           B, Hq, Hkv, Nq, Nk, D, float(scale), qbs, qhs, kbs, khs, int(bool(is_causal)), fa_dtype, stream)
+        st = lib.fa_fwd_exv(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+                            B, Hq, Hkv, Nq, Nk, D, float(scale), qbs, qhs, kbs, khs, int(bool(is_causal)), fa_dtype, VARIANTS[variant], stream)
     if st != 0:
         raise FaError(st, lib.fa_last_error().decode())
     return out, lse

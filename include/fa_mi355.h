@@ -133,6 +133,13 @@ int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse,
               long long q_batch_stride, long long q_head_stride,
               long long kv_batch_stride, long long kv_head_stride,
               int is_causal, int dtype, void *hip_stream);
+/* fa_fwd_ex with the kernel named by the caller: FA_VARIANT_AUTO (= fa_fwd_ex), FA_VARIANT_MFMA, FA_VARIANT_MFMA_EXACT (no pre-scaled
+ * query operand), FA_VARIANT_MFMA16 (f16 / bf16, D = 64) or FA_VARIANT_MFMA_SPLITKV (D = 64, 128); any other variant: FA_ERR_UNSUPPORTED. */
+int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
+               int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
+               long long q_batch_stride, long long q_head_stride,
+               long long kv_batch_stride, long long kv_head_stride,
+               int is_causal, int dtype, int variant, void *hip_stream);
 
 /*
  * Backward of the operator (row f1 of the scope table): the reference binds it as

@@ -103,6 +103,13 @@ def test_ex_and_bwd_reject_bad_strides_and_oversized_grids(fa):
     assert lib.fa_fwd_ex(ok, ok, ok, ok, None, 65536, 65536, 65536, 128, 128, 64, 0.125, 65536 * 128 * 64, 128 * 64,
                          65536 * 128 * 64, 128 * 64, 0, 2, None) == -1 and b"grid" in lib.fa_last_error()
     assert lib.fa_fwd_ex(ok, ok, ok, ok, None, 2, 2, 2, 128, 128, 64, 0.125, -16384, 8192, 16384, 8192, 0, 2, None) == -1
+    # one head of 4 GiB minus one tile: refused with the same +128-row margin as fa_fwd (the staging loops address past the end)
+    n_big = (1 << 32) // (64 * 2) - 64
+    assert lib.fa_fwd_ex(ok, ok, ok, ok, None, 1, 1, 1, 128, n_big, 64, 0.125, 128 * 64, 128 * 64, n_big * 64, n_big * 64, 0, 2, None) == -1 \
+        and b"4 GiB" in lib.fa_last_error()
+    # fa_fwd_exv: kernels that do not take the generalised problem are refused by name (no silent substitute)
+    assert lib.fa_fwd_exv(ok, ok, ok, ok, None, 1, 4, 2, 128, 128, 64, 0.125, 4 * 8192, 8192, 2 * 8192, 8192, 0, 2, 5, None) == -2 \
+        and b"mfma_pp" in lib.fa_last_error()
     f = P(0x2000)
     assert lib.fa_bwd(ok, ok, ok, ok, ok, f, f, f, f, f, 65536, 65536, 128, 64, 0.125, 65536 * 8192, 8192, 0, 2, None) == -1 \
         and b"grid" in lib.fa_last_error()

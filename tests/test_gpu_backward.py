@@ -171,7 +171,7 @@ def test_backward_partial_last_key_tile_with_strongly_negative_scores(fa, oracle
         do = oracle_mod.round_to(rng.uniform(-1, 1, (B, Hq, Nq, D)).astype(np.float32), dtype)
         qd, kd, vd, dod = (to_dev(x, dtype) for x in (q, k, v, do))
         o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=False)
-        assert lse.max().item() < -12.0  # the regime the advisory describes: exp(-lse) is beyond the f16 range
+        assert lse.max().item() < -11.2  # the regime the advisory describes: exp(-lse) is beyond the f16 range
         dq, dk, dv = fa.flash_attention_backward(qd, kd, vd, o, dod, lse, is_causal=False)
         torch.cuda.synchronize()
         for name, g, ref in zip(("dq", "dk", "dv"), (dq, dk, dv), rect_reference(q, k, v, do, False)):

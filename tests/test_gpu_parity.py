@@ -350,23 +350,36 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
         k = oracle_mod.round_to(oracle_mod.init_random(B * Hkv * Nk * D, int(rng.integers(1, 1 << 20))).reshape(B, Hkv, Nk, D), dtype)
         v = oracle_mod.round_to(oracle_mod.init_random(B * Hkv * Nk * D, int(rng.integers(1, 1 << 20))).reshape(B, Hkv, Nk, D), dtype)
         qd, kd, vd = (to_dev(x, dtype) for x in (q, k, v))
-        o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal)
-        torch.cuda.synchronize()
         o64, l64 = oracle_mod.attn_fwd_ex_f64(q, k, v, causal)
-        # which kernel fa_fwd_ex runs (include/fa_mi355.h): the split-KV kernel for at most 64 blocks of 128 query rows against
-        # more than 64 keys at head_dim 64 (it scales every score in fp32), else the 128-row kernel (pre-scaled operand)
-        small = D == 64 and Nk > 64 and B * Hq * ((Nq + 127) // 128) <= 64
-        pre = D <= 128 and not small
-        assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype], (B, Hq, Hkv, Nq, Nk, D, causal)
-        assert np.abs(lse.cpu().numpy() - l64).max() < lse_tol(dtype, pre, q, k), (B, Hq, Hkv, Nq, Nk, D, causal)
-        if pre:  # strict vs the oracle on the operand the kernel really multiplies
-            o64, l64 = oracle_mod.attn_fwd_ex_f64(effective_q(oracle_mod, q, dtype), k, v, causal, LN2)
-            assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype] and np.abs(lse.cpu().numpy() - l64).max() < 1e-4
-        if Nq == Nk:  # GQA == MHA on repeated K/V heads, bit for bit, through the same kernel by name
-            g = Hq // Hkv
-            o2, l2 = fa.flash_attention_forward(qd, kd.repeat_interleave(g, 1).contiguous(), vd.repeat_interleave(g, 1).contiguous(),
-                                                is_causal=causal, variant="mfma_splitkv" if small else "mfma")
-            assert torch.equal(o, o2) and torch.equal(lse, l2)
+        o64q, l64q = oracle_mod.attn_fwd_ex_f64(effective_q(oracle_mod, q, dtype), k, v, causal, LN2)
+        # which kernel fa_fwd_ex's AUTO runs (include/fa_mi355.h): the split-KV kernel for at most 64 blocks of 128 query rows against
+        # more than 64 keys at head_dim 64 (it scales every score in fp32), else the 128-row kernel (pre-scaled operand) -- its
+        # 16x16x32 form for long key sequences on large head_dim-64 grids; every kernel that takes the generalised problem also by name
+        blocks = B * Hq * ((Nq + 127) // 128)
+        small = D == 64 and Nk > 64 and blocks <= 64
+        auto = "mfma_splitkv" if small else "mfma16" if (D == 64 and Nk >= 2048 and blocks > 512) else "mfma"
+        for variant in ["auto", "mfma", "mfma_exact"] + (["mfma16", "mfma_splitkv"] if D == 64 else []):
+            name = auto if variant == "auto" else variant
+            pre = {"mfma": int(D <= 128), "mfma16": 2}.get(name, 0)
+            o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal, variant=variant)
+            torch.cuda.synchronize()
+            what = (variant, B, Hq, Hkv, Nq, Nk, D, causal)
+            assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype], what
+            assert np.abs(lse.cpu().numpy() - l64).max() < lse_tol(dtype, pre, q, k), what
+            if pre:  # strict vs the oracle on the operand the kernel really multiplies
+                assert np.abs(o.float().cpu().numpy() - o64q).max() < TOL_O[dtype], what
+                assert np.abs(lse.cpu().numpy() - l64q).max() < 1e-4 + rowsum_term(dtype, pre), what
+            if Nq == Nk:  # GQA == MHA on repeated K/V heads, bit for bit, through the same kernel by name
+                g = Hq // Hkv
+                o2, l2 = fa.flash_attention_forward(qd, kd.repeat_interleave(g, 1).contiguous(), vd.repeat_interleave(g, 1).contiguous(),
+                                                    is_causal=causal, variant=name)
+                assert torch.equal(o, o2) and torch.equal(lse, l2), what
+    # a kernel that does not take grouped heads / Nq != Nk is refused by name, never silently replaced
+    x = to_dev(np.zeros((1, 4, 64, 64), np.float32), dtype)
+    for variant in ("mfma_pp", "mfma_split2", "mfma_h64s2", "tiled_v2", "naive"):
+        with pytest.raises(fa.FaError) as e:
+            fa.flash_attention_forward(x, x[:, :2].contiguous(), x[:, :2].contiguous(), variant=variant)
+        assert e.value.status == -2
     if dtype == "bf16":  # the same generalised path with fp8 (e4m3) inputs: equal to bf16 on the same values up to fp32 summation order
         q = oracle_mod.round_to(oracle_mod.init_random(2 * 8 * 96 * 64, 5).reshape(2, 8, 96, 64) * 2, "fp8")
         k = oracle_mod.round_to(oracle_mod.init_random(2 * 2 * 333 * 64, 6).reshape(2, 2, 333, 64) * 2, "fp8")
@@ -554,7 +567,10 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
         (1, 8, 256, 128, "bf16", False, "mfma"),           # head_dim 128, 16 blocks, N < 512: the plain kernel
         (1, 16, 2048, 128, "bf16", True, "mfma_split2"),   # 256 blocks of 128 rows, N < 4096
         (1, 32, 2048, 64, "bf16", True, "mfma_split2"),    # causal, 512 blocks, N >= 2048: still the eight-wave form
-        (1, 32, 2048, 64, "bf16", False, "mfma"),          # ... not without the mask
+        (1, 32, 2048, 64, "bf16", False, "mfma16"),        # ... not without the mask: head_dim 64, 16-bit inputs, N >= 2048 -> the 16x16x32 kernel
+        (1, 80, 2048, 64, "f16", True, "mfma16"),          # causal, 1280 blocks of 128 rows (past the eight-wave form), N >= 2048
+        (1, 80, 2047, 64, "bf16", True, "mfma"),           # ... N < 2048: the 32x32x16 kernel
+        (1, 80, 2048, 64, "fp8", True, "mfma"),            # ... fp8 inputs have no 16x16x32 kernel
         (1, 64, 1024, 64, "bf16", True, "mfma"),           # ... and not at N = 1024
         (1, 32, 4096, 128, "bf16", True, "mfma"),          # long head_dim-128 sequences: the 128-row kernel (round 2: paired-block)
         (1, 4, 300, 96, "bf16", True, "mfma"),             # head dims only the 128-row kernel has
