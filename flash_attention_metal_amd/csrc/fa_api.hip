@@ -37,6 +37,7 @@ const char *fa_variant_name(int v) {
     case FA_VARIANT_MFMA_EXACT: return "mfma_exact";
     case FA_VARIANT_MFMA_H64S2: return "mfma_h64s2";
     case FA_VARIANT_MFMA16: return "mfma16";
+    case FA_VARIANT_MFMA_FP8PV: return "mfma_fp8pv";
     default: return "?";
   }
 }
@@ -72,6 +73,7 @@ int fa_supported(int dtype, int variant, int D) {
     case FA_VARIANT_MFMA_EXACT: return fa::mfma_supported(dtype, D);
     case FA_VARIANT_MFMA_H64S2: return fa::mfma_h64s2_supported(dtype, D);
     case FA_VARIANT_MFMA16: return fa::mfma16_supported(dtype, D);
+    case FA_VARIANT_MFMA_FP8PV: return fa::fp8pv_supported(dtype, D);
     default: return 0;
   }
 }
@@ -129,6 +131,7 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
     case FA_VARIANT_MFMA_SPLIT2: snprintf(name, sizeof(name), "fa::fwd_mfma_split2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_H64S2: snprintf(name, sizeof(name), "fa::fwd_mfma_h64s2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA16: snprintf(name, sizeof(name), "fa::fwd_mfma16_kernel<%s, %d, %s>", tag, D, c); break;
+    case FA_VARIANT_MFMA_FP8PV: snprintf(name, sizeof(name), "fa::fwd_fp8_kernel<%d, %s>", D, c); break;
     case FA_VARIANT_MFMA:
       snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s, %s>", tag, D, c,
                (dtype != FA_DTYPE_FP8_E4M3 && D <= 128) ? "true" : "false");  // pre-scaled operand where it exists
@@ -203,6 +206,7 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
     case FA_VARIANT_MFMA_SPLIT2: e = fa::launch_mfma_split2(p, dtype, s); break;
     case FA_VARIANT_MFMA_H64S2: e = fa::launch_mfma_h64s2(p, dtype, s); break;
     case FA_VARIANT_MFMA16: e = fa::launch_mfma16(p, dtype, s); break;
+    case FA_VARIANT_MFMA_FP8PV: e = fa::launch_fp8pv(p, dtype, s); break;
     default: e = fa::launch_mfma(p, dtype, s); break;
   }
   if (e == hipErrorNoDevice || e == hipErrorInvalidDevice)

@@ -59,6 +59,8 @@ hipError_t launch_mfma_h64s2(const Params &p, int dtype, hipStream_t s);
 bool mfma_h64s2_supported(int dtype, int D);
 hipError_t launch_mfma16(const Params &p, int dtype, hipStream_t s);
 bool mfma16_supported(int dtype, int D);
+hipError_t launch_fp8pv(const Params &p, int dtype, hipStream_t s);
+bool fp8pv_supported(int dtype, int D);
 hipError_t launch_pp(const Params &p, int dtype, hipStream_t s);
 hipError_t launch_splitkv(const Params &p, int dtype, hipStream_t s);
 

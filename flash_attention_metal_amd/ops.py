@@ -17,7 +17,7 @@ import torch
 from ._lib import load_library
 
 DTYPES = {"f32": 0, "f16": 1, "bf16": 2, "fp8_e4m3": 3}
-VARIANTS = {"auto": 0, "naive": 1, "tiled": 2, "tiled_v2": 3, "mfma": 4, "mfma_pp": 5, "mfma_splitkv": 6, "mfma_split2": 7, "mfma_exact": 8, "mfma_h64s2": 9, "mfma16": 10}
+VARIANTS = {"auto": 0, "naive": 1, "tiled": 2, "tiled_v2": 3, "mfma": 4, "mfma_pp": 5, "mfma_splitkv": 6, "mfma_split2": 7, "mfma_exact": 8, "mfma_h64s2": 9, "mfma16": 10, "mfma_fp8pv": 11}
 
 _TORCH2FA = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 if hasattr(torch, "float8_e4m3fn"):

@@ -67,9 +67,11 @@ enum fa_variant {
   FA_VARIANT_MFMA_H64S2 = 9, /* same operator, 64 query rows per workgroup: four waves, the two wave pairs take the even / odd
                             KV tiles and merge once (twice the workgroups, half the sequential tiles of a block): grids
                             whose critical path is the heaviest causal block (f16 / bf16, head_dim 64) */
-  FA_VARIANT_MFMA16 = 10 /* FA_VARIANT_MFMA's workgroup (128 query rows, pre-scaled query operand) with every product on
+  FA_VARIANT_MFMA16 = 10, /* FA_VARIANT_MFMA's workgroup (128 query rows, pre-scaled query operand) with every product on
                             v_mfma_f32_16x16x32 instead of 32x32x16: the chip holds a higher clock on that shape under
                             power-limited loops (f16 / bf16, head_dim 64) */
+  FA_VARIANT_MFMA_FP8PV = 11 /* fp8 inputs, head_dim 64: BOTH products on the scaled fp8 MFMA -- the probabilities are rounded to e4m3
+                            for the PV product (FA_VARIANT_MFMA / _EXACT keep them in bf16); see "fp8 probabilities" below */
 };
 
 /* status codes (0 = success, negative = error; text via fa_last_error()) */

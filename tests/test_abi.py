@@ -38,7 +38,7 @@ def test_header_symbols_all_exported(fa):
 def test_version_and_names(fa):
     lib = fa.load_library()
     assert lib.fa_version() == 400
-    assert [lib.fa_variant_name(i).decode() for i in range(11)] == ["auto", "naive", "tiled", "tiled_v2", "mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2", "mfma16"]
+    assert [lib.fa_variant_name(i).decode() for i in range(12)] == ["auto", "naive", "tiled", "tiled_v2", "mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2", "mfma16", "mfma_fp8pv"]
     assert [lib.fa_dtype_name(i).decode() for i in range(4)] == ["f32", "f16", "bf16", "fp8_e4m3"]
 
 

@@ -59,6 +59,13 @@ def is_prescaled(fa, dtype, variant, B, H, N, D, causal=False):
 ROWSUM_EPS = {"f16": 2.0 ** -11, "bf16": 2.0 ** -8}
 
 
+# The all-fp8 kernel (csrc/fa_fp8_kernel.hip, variant mfma_fp8pv) rounds every probability to e4m3 (3 mantissa bits) for the PV product:
+# each weight moves by a factor within 1 +- 2^-4, so |O - exact| <= 2^-4 * max|V| on top of the other kernels' bar (far less where a
+# row has many comparable keys: the roundings are independent). The row sum -- and with it LSE -- adds the UNROUNDED probabilities.
+def fp8pv_term(variant, dtype, v):
+    return 2.0 ** -4 * float(np.abs(v).max()) if (variant == "mfma_fp8pv" and dtype == "fp8") else 0.0
+
+
 def rowsum_term(dtype, prescaled):
     return ROWSUM_EPS.get(dtype, 0.0) if prescaled == 2 else 0.0
 
