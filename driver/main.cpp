@@ -413,9 +413,11 @@ static void run_configs(const Options &opt, std::ofstream &ext) {
       {"c2", 1, 8, 1024, 64, FA_DTYPE_F16, false},                          // "auto": the split-KV matrix-core kernel on this small grid
       {"c2_v2", 1, 8, 1024, 64, FA_DTYPE_F16, false, FA_VARIANT_TILED_V2},  // the kernel BASELINE configs[1] names (kernels.metal:462-596)
       {"c2_mfma", 1, 8, 1024, 64, FA_DTYPE_F16, false, FA_VARIANT_MFMA},    // the 128-row matrix-core kernel, for comparison
-      {"c3", 4, 16, 4096, 64, FA_DTYPE_BF16, true},
+      {"c3", 4, 16, 4096, 64, FA_DTYPE_BF16, true},                          // "auto": the 16x16x32 kernel (round 4)
+      {"c3_mfma32", 4, 16, 4096, 64, FA_DTYPE_BF16, true, FA_VARIANT_MFMA},  // the 32x32x16 kernel of rounds 1-3, for comparison
       {"c4", 8, 32, 16384, 128, FA_DTYPE_BF16, true},  // 8-GPU config: on G GPUs, G/8 of its (b,h) slices
-      {"c5", 4, 16, 8192, 64, FA_DTYPE_FP8_E4M3, true},  // fp8 in / fp32 accumulate / bf16 out (B,H assumed as c3)
+      {"c5", 4, 16, 8192, 64, FA_DTYPE_FP8_E4M3, true},  // fp8 in / fp32 accumulate / bf16 out (B,H assumed as c3); "auto": both products on the fp8 pipe
+      {"c5_bf16p", 4, 16, 8192, 64, FA_DTYPE_FP8_E4M3, true, FA_VARIANT_MFMA},  // probabilities kept in bf16 (score product alone on the fp8 pipe)
   };
   for (const Config &c0 : cfgs) {
     for (int g = 1; g <= G; g *= 2) {

@@ -117,6 +117,9 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   // core -- config 3 +2 %, N >= 4096 non-causal / N >= 8192 causal +4.5..5.7 %; level at N = 2048, 1-2 % behind at N = 1024 (its
   // first tile pays a second score pass) (profiles/r04/ab_mfma16_ones_vs_adds.log)
   if (fa::mfma16_supported(dtype, D) && N >= 2048) return FA_VARIANT_MFMA16;
+  // fp8 inputs, head_dim 64, grids that fill the chip: both products on the fp8 matrix pipe (config 5: 1215-1245 -> 1364-1461 TFLOP/s,
+  // profiles/r04/ab_fp8pv_*.log). Its probabilities are e4m3 (include/fa_mi355.h, "fp8 probabilities"); FA_VARIANT_MFMA keeps them bf16
+  if (fa::fp8pv_supported(dtype, D)) return FA_VARIANT_MFMA_FP8PV;
   return FA_VARIANT_MFMA;
 }
 

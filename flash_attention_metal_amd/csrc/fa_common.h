@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "../../include/fa_mi355.h"
 
 namespace fa {
@@ -75,6 +79,21 @@ bool bwd_supported(int dtype, int D);
 hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
                       float *dq, float *dk, float *dv, float *ws, int B, int H, int Hkv, int N, int Nk, int D, float scale,
                       long long bs, long long hs, long long kv_bs, long long kv_hs, int causal, int dtype, hipStream_t s);
+
+// ---- host-side launch helper shared by every kernel file that needs more than 48 KiB of dynamic LDS
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch.
+inline hipError_t set_dyn_lds_once(const void *fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void *, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({fn, dev})) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert({fn, dev});
+  return e;
+}
 
 // ---- element load/store helpers for the scalar kernels -------------------
 __device__ __forceinline__ float ld_elem(const float *p, long long i) { return p[i]; }

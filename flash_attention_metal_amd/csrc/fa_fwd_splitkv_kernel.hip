@@ -29,7 +29,6 @@ __global__ __launch_bounds__((D == 64 ? 512 : 256), 1) void fwd_splitkv_kernel(P
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
   constexpr int RB = D * 2;
-  constexpr int CPR = D / 8;
   constexpr int KS = D / 16;
   constexpr int DB = D / 32;
   constexpr int TILE = BN * RB;               // one K (or V) tile in LDS

@@ -283,20 +283,6 @@ __device__ __forceinline__ void head_bases(int bh, const Params &p, long long &b
 
 // ---- host-side launch helpers shared by the matrix-core kernel files ---------------------------
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) instead of on every launch.
-inline hipError_t set_dyn_lds_once(const void *fn, int bytes) {
-  static std::mutex mu;
-  static std::set<std::pair<const void *, int>> done;
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  std::lock_guard<std::mutex> g(mu);
-  if (done.count({fn, dev})) return hipSuccess;
-  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  if (e == hipSuccess) done.insert({fn, dev});
-  return e;
-}
-
 // Causal issue order: heaviest-first within groups of `head_group` heads (map_block above).
 // One global group balances best. Measured on config 3 (1 MiB of K+V per head, 8 heads per XCD
 // in flight): 279 MB fetched per launch vs 140 MB with 32-head groups (algorithmic reads 101 MB),

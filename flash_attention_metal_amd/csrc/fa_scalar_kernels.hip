@@ -424,12 +424,8 @@ hipError_t launch_tiled(const Params &p, int dtype, hipStream_t s) {
 template <typename T, int D>
 static hipError_t launch_tiled_v2_one(const Params &p, hipStream_t s) {
   auto kern = tiled_v2_kernel<T, D>;
-  static std::once_flag once[8];  // per device ordinal (the attribute is per device)
-  int dev = 0;
-  hipError_t e = hipGetDevice(&dev);
-  if (e != hipSuccess) return e;
-  hipError_t attr = hipSuccess;
-  std::call_once(once[dev & 7], [&] { attr = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_lds_bytes<D>()); });
+  // once per (kernel, device), marked done only on success (as the matrix-core launchers do)
+  const hipError_t attr = set_dyn_lds_once((const void *)kern, (int)v2_lds_bytes<D>());
   if (attr != hipSuccess) return attr;
   dim3 grid((p.N + V2_BR - 1) / V2_BR, p.H, p.B), block(64 * V2_NW);
   (void)hipGetLastError();

@@ -8,9 +8,9 @@ registered for the CUDA/HIP device only -- there is deliberately no CPU implemen
 
 Autograd: the op carries a backward formula that saves (q, k, v, o, lse) and calls fa_bwd()
 (csrc/fa_bwd_kernels.hip; the math of /root/reference/kernels.metal:905-1265, which consumes the
-forward's LSE). Shapes fa_bwd has no kernel for (head dims other than 64 / 128, fp8 / fp32 inputs,
-grouped heads, Nq != Nk) raise instead of returning a silent zero gradient; so does a gradient
-flowing into the LSE output.
+forward's LSE), through fa_bwd_ex: grouped-query heads (Hq % Hkv == 0) and Nq != Nk (causal: Nk >= Nq) are
+differentiated too. Shapes fa_bwd_ex has no kernel for (head dims other than 64 / 128, fp8 / fp32 inputs)
+raise instead of returning a silent zero gradient; so does a gradient flowing into the LSE output.
 """
 from __future__ import annotations
 

@@ -103,16 +103,30 @@ enum fa_status {
  * unspecified output values (never a fault).
  *
  * LSE accuracy. The reference never checks L_out (main.mm:1083 only feeds it to its backward) and forms its scores in
- * half precision (kernels.metal:709-712). Here every sum is fp32. FA_VARIANT_MFMA and FA_VARIANT_MFMA_SPLIT2 with
- * f16 / bf16 inputs and D <= 128 (the kernels FA_VARIANT_AUTO picks for BASELINE configs 2 and 3) multiply the query
- * operand by scale*log2(e) and round it to the input type ONCE per 128-row block, so that the matrix core delivers
- * the exponent of every probability directly (replaces the per-score scale-and-subtract of kernels.metal:763-771):
- * the result is the exact operator applied to a Q' with |Q' - Q| <= eps*|Q| element-wise, eps = 2^-9 (bf16) /
- * 2^-12 (f16), half an ulp of the input type. Consequently
+ * half precision (kernels.metal:709-712). Here every sum is fp32. The kernels with a PRE-SCALED query operand -- FA_VARIANT_MFMA,
+ * FA_VARIANT_MFMA_SPLIT2, FA_VARIANT_MFMA_H64S2 and FA_VARIANT_MFMA16 with f16 / bf16 inputs and D <= 128 (what FA_VARIANT_AUTO
+ * picks for BASELINE configs 3 and 4, and the 128-row route of fa_fwd_ex) -- multiply the query operand by scale*log2(e) and round
+ * it to the input type ONCE per block of query rows, so that the matrix core delivers the exponent of every probability directly
+ * (replaces the per-score scale-and-subtract of kernels.metal:763-771): the result is the exact operator applied to a Q' with
+ * |Q' - Q| <= eps*|Q| element-wise, eps = 2^-9 (bf16) / 2^-12 (f16), half an ulp of the input type. Consequently
  *     |lse - exact| <= 1e-4 + eps * scale * |q_i|_2 * max_j |k_j|_2        (row i),
  * i.e. relative to the score magnitude (measured on BASELINE config 3, U(-1,1) inputs: max 1.0e-3, rms 4e-5 for
  * bf16; 1.3e-4 / 5e-6 for f16), while O keeps the tolerance of the other kernels (max|O - exact| 3.1e-3 vs 2.9e-3
- * without the pre-scaling on config 3). Every other kernel / dtype: |lse - exact| <= 1e-4 for |lse| <= ~10.
+ * without the pre-scaling on config 3). FA_VARIANT_MFMA16 additionally takes its row sums from the matrix core, i.e. it adds the
+ * probabilities AFTER their rounding to the input type (the very values the PV product multiplies: O's weights then add up to
+ * exactly 1): ln(l) carries that rounding, at most 2^-8 (bf16) / 2^-11 (f16) on top of the bound above and far less on average
+ * (measured: 4e-4 at N = 128, below 1e-4 from N = 1024 on, bf16). Every other kernel / dtype (FA_VARIANT_MFMA_EXACT, the split-KV
+ * and paired-block kernels, fp8 inputs): |lse - exact| <= 1e-4 for |lse| <= ~10.
+ *
+ * fp8 probabilities. FA_VARIANT_MFMA_FP8PV (e4m3 inputs, D = 64; FA_VARIANT_AUTO's choice for grids that fill the chip) runs BOTH
+ * products on the fp8 matrix pipe: the probabilities are rounded to e4m3 (3 mantissa bits) on their way into the PV product, as the
+ * inputs themselves were. Every softmax weight moves by a factor within 1 +- 2^-4, so
+ *     |O - exact| <= 2^-4 * max_j |v_j|     (plus the bf16 rounding of O),
+ * reached only by rows with one or two visible keys; the roundings of a row's weights are independent, so rows with many comparable
+ * keys see a small fraction of it (measured on BASELINE config 5, U(-1,1) inputs: max 2.3e-2 over the first rows of the causal mask,
+ * below the other kernels' 6e-3 on every row with more than 1024 keys). Weights below 2^-13 of the row's reference are flushed to
+ * zero (e4m3's range). l and LSE add the UNROUNDED probabilities: LSE keeps the 1e-4 bound. FA_VARIANT_MFMA / FA_VARIANT_MFMA_EXACT
+ * with fp8 inputs keep the probabilities in bf16 (the score product alone on the fp8 pipe).
  */
 int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
            int B, int H, int N, int D, float scale,

@@ -580,13 +580,14 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
         (1, 32, 2048, 64, "bf16", False, "mfma16"),        # ... not without the mask: head_dim 64, 16-bit inputs, N >= 2048 -> the 16x16x32 kernel
         (1, 80, 2048, 64, "f16", True, "mfma16"),          # causal, 1280 blocks of 128 rows (past the eight-wave form), N >= 2048
         (1, 80, 2047, 64, "bf16", True, "mfma"),           # ... N < 2048: the 32x32x16 kernel
-        (1, 80, 2048, 64, "fp8", True, "mfma"),            # ... fp8 inputs have no 16x16x32 kernel
+        (1, 80, 2048, 64, "fp8", True, "mfma_fp8pv"),      # ... fp8 inputs have no 16x16x32 kernel: the all-fp8 kernel on grids that fill the chip
         (1, 64, 1024, 64, "bf16", True, "mfma"),           # ... and not at N = 1024
         (1, 32, 4096, 128, "bf16", True, "mfma"),          # long head_dim-128 sequences: the 128-row kernel (round 2: paired-block)
         (1, 4, 300, 96, "bf16", True, "mfma"),             # head dims only the 128-row kernel has
         (1, 8, 1024, 64, "fp8", True, "mfma_splitkv"),
         (1, 40, 1024, 64, "fp8", True, "mfma_split2"),     # fp8, causal, 320 blocks, N >= 1024: the eight-wave form
-        (1, 80, 1024, 64, "fp8", True, "mfma"),            # 640 blocks: the plain kernel
+        (1, 80, 1024, 64, "fp8", True, "mfma_fp8pv"),      # 640 blocks: past the eight-wave form, the all-fp8 kernel
+        (1, 80, 1024, 128, "fp8", True, "mfma"),           # ... which exists for head_dim 64 only
     ]
     for (B, H, N, D, dtype, causal, want) in cases:
         fdt = fa.DTYPES[{"fp8": "fp8_e4m3"}.get(dtype, dtype)]
@@ -602,7 +603,7 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
             rows = np.unique(np.concatenate([[0, N // 2, N - 1], np.arange(0, N, max(1, N // 64))])).astype(np.int32)
             o64, l64 = oracle_mod.attn_rows_f64(q[0, h], k[0, h], v[0, h], rows, causal)
             pre = is_prescaled(fa, dtype, "auto", B, H, N, D, causal)
-            tol = TOL_O["f16"] if dtype == "f16" else TOL_O["bf16"]
+            tol = (TOL_O["f16"] if dtype == "f16" else TOL_O["bf16"]) + fp8pv_term(want, dtype, v[0, h])
             assert np.abs(o_a[0, h].float().cpu().numpy()[rows] - o64).max() < tol, (want, h)
             assert np.abs(l_a[0, h].cpu().numpy()[rows] - l64).max() < lse_tol(dtype, pre, q[0, h], k[0, h]), (want, h)
 

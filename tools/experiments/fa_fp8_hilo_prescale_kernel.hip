@@ -1,0 +1,351 @@
+// fa_fp8_kernel.hip -- the operator for OCP e4m3 inputs with BOTH products on the fp8 matrix pipe (variant "mfma_fp8pv").
+//
+// BASELINE.json configs[4]: "fp8 Q/K/V with fp32 accumulate (CDNA4 fp8 MFMA)". Same math as the other matrix-core kernels (replaces
+// /root/reference/kernels.metal:600-883; mask kernels.metal:748, L = m + ln(l) kernels.metal:862-864). fa_mfma_kernel.hip runs only
+// the score product on v_mfma_scale_f32_32x32x64_f8f6f4 and widens V to bf16 on its way to LDS (a VGPR round trip, conversion VALU,
+// twice the LDS bytes, PV at the bf16 rate). Here (one workgroup = 4 waves = 128 query rows, a wave owns 32):
+//   * K AND V stay e4m3 in LDS (rows of D bytes) and travel global -> LDS by LDS-DMA, swizzle on the source address
+//   * S^T = K.Q^T on the scaled fp8 MFMA (exact e4m3 products, 64 head-dim elements per instruction) with a PRE-SCALED query operand:
+//     c.Q (c = scale.log2 e) cannot be an e4m3 value, so it is split once per block into TWO e4m3 operands, Q~ = (hi + lo / 16) . 2^e
+//     with hi = rne8(f.Q), lo = rne8(16 (f.Q - hi)), c = f . 2^e, f in [0.5, 1) -- the powers of two ride in the MFMA's E8M0 block scales
+//     -- and every score chain is two MFMAs, K.hi then K.lo, on top of the C operand -reference: the matrix core hands out the exponent
+//     of every probability and the loop loses its 32 v_fma per tile for 2 more MFMAs (the matrix pipe is far from busy in this
+//     kernel). |Q~ - c.Q| <= 2^-8 |c.Q| element-wise: the bf16 kernels' pre-scaled operand at twice its rounding
+//   * P is rounded to e4m3 (v_cvt_pk_fp8_f32) and O^T += V^T.P^T runs on the same instruction, 64 keys per MFMA: the B operand's k
+//     index (32h + j) is key 32(j >> 4) + 8((j >> 2) & 3) + 4h + (j & 3) -- the order the scores sit in the accumulator -- and V^T is
+//     fetched in that order by ds_read_b64_tr_b8 (per 16-lane group: 8 rows x 16 bytes, lane 2q + p supplies row q's bytes 8p..8p+7,
+//     lane i receives column i with row q in byte q; probed on the hardware: tools/probes/probe_tr8.hip)
+//   * e4m3 holds 2^-9 .. 448 with 3 mantissa bits: the probabilities are formed against a reference SHIFT = 3 (log2 units) BELOW the
+//     row maximum (P' = 8 P <= 8 when the reference is set; O and l carry the same factor, it cancels), which leaves 2^-13 of the row
+//     maximum above the flush-to-zero floor, and the reference is renewed when a lane's 32 probabilities add up to more than 448
+//     (then none of them can exceed the e4m3 range -- the conversion does not saturate: 480 -> NaN, probed). The price is the rounding
+//     of every probability to 3 mantissa bits: include/fa_mi355.h, "fp8 probabilities".
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "fa_mfma_common.h"
+
+#ifndef FA8_SHIFT
+#define FA8_SHIFT 3.0f  // log2 units: the reference sits this far BELOW the row maximum found when it was last set
+#endif
+#ifndef FA8_SUM_LIMIT
+#define FA8_SUM_LIMIT 448.0f  // a lane's 32 probabilities of a tile may add up to this before the reference is renewed (e4m3 max)
+#endif
+#ifndef FA8_OCC
+#define FA8_OCC 4
+#endif
+
+namespace fa {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+// the scaled fp8 MFMA with unit scales (E8M0 0x7f = 2^0): D = A(e4m3, 32 x 64) . B(e4m3, 64 x 32) + C
+__device__ __forceinline__ f32x16 mfma_f8(i32x8 a, i32x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+// ... with the B operand's blocks scaled by 2^(sb - 127) (sb: the E8M0 byte, replicated)
+__device__ __forceinline__ f32x16 mfma_f8_sb(i32x8 a, i32x8 b, f32x16 c, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, sb);
+}
+
+template <int D, bool CAUSAL>
+__device__ __forceinline__ void fwd_fp8_body(const Params &p) {
+  static_assert(D == 64, "head dim of the all-fp8 kernel");
+  constexpr int RW = BM / WM;     // waves
+  constexpr int RB = D;           // row bytes of K / V (global and LDS)
+  constexpr int ORB = 2 * D;      // row bytes of the bf16 O tile
+  constexpr int TILE = BN * RB;   // bytes of one K (or V) tile
+  constexpr int DB = D / 32;      // 32-wide d blocks of O^T
+  constexpr int CPO = ORB / 16;   // 16-byte chunks of an O row
+
+  extern __shared__ __attribute__((aligned(16))) char smem_generic[];
+  lds_char *smem = (lds_char *)smem_generic;
+  lds_char *Kbuf = smem;             // [2][BN][RB], chunks swizzled
+  lds_char *Vbuf = smem + 2 * TILE;  // [2][BN][RB], chunks swizzled
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31;  // query within the wave / key row within a 32-key block / d within a 32-wide block
+  const int h = lane >> 5;  // lane half
+
+  int bh, qb;
+  map_block<CAUSAL>(blockIdx.x, p, bh, qb);
+  long long base, base_kv;
+  head_bases(bh, p, base, base_kv);
+  const int coff = p.Nk - p.N;
+  const int q0 = qb * BM;
+  const int qw0 = q0 + wave * WM;
+  const int qrow = qw0 + r;
+
+  const unsigned head_bytes = (unsigned)p.N * RB, kv_head_bytes = (unsigned)p.Nk * RB;
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.q + base), 0, head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.k + base_kv), 0, kv_head_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.v + base_kv), 0, kv_head_bytes, 0x00020000);
+
+  // ---- Q fragment (B operand of K.Q^T): lane (r, h) holds Q[qrow][32h .. 32h+31] (any k order works as long as K uses the same)
+  i32x8 qf;
+  {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + 32 * h, 0, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + 32 * h + 16, 0, 0);
+    qf = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  }
+
+  // ---- per-lane LDS addresses (absolute, opaque to hipcc)
+  // K: row (32kb + r), bytes 32h .. 32h+31 = 16-byte chunks 2h, 2h+1, swizzled by (r >> 2) & 3 (conflict-free ds_read_b128)
+  const int kx = (r >> 2) & 3;
+  const lds_char *kptr0 = Kbuf + r * RB + (((2 * h) ^ kx) << 4), *kptr1 = Kbuf + r * RB + (((2 * h + 1) ^ kx) << 4);
+  asm volatile("" : "+v"(kptr0), "+v"(kptr1));
+  // V: ds_read_b64_tr_b8. 16-lane group (h, c16 = (lane >> 4) & 1) covers d columns 32db + 16c16 ..+15; its lane 2q + pp supplies the
+  // address of row q of the group's 8 rows, bytes 8pp .. 8pp+7: rows q = 0..3 -> keys 8g + 4h + q, q = 4..7 -> keys 8(g+1) + 4h + (q-4)
+  // (g = 0, 2 per read; + 32kb), so the two result dwords are elements j = 16kb + 4g + 0..3 and 16kb + 4(g+1) + 0..3 of the operand.
+  // Image: 16-byte chunk index ^ (((row >> 3) & 1) << 1): the two 4-row halves of a read sit in different 32-byte halves of the bank row.
+  const int vi = lane & 15, vq = vi >> 1, vpp = vi & 1, c16 = (lane >> 4) & 1;
+  const int vrow = 8 * (vq >> 2) + 4 * h + (vq & 3);
+  const lds_char *vptr[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db) {
+    vptr[db] = Vbuf + vrow * RB + (((2 * db + c16) ^ (((vq >> 2) & 1) << 1)) << 4) + 8 * vpp;
+    asm volatile("" : "+v"(vptr[db]));
+  }
+
+  const int kv_end = CAUSAL ? min(p.Nk, q0 + BM + coff) : p.Nk;
+  const int nT = (kv_end + BN - 1) / BN;
+
+  // ---- LDS-DMA staging: one 1-KiB piece (16 rows) of K and one of V per wave and tile; the swizzles sit on the SOURCE address
+  static_assert(BN * RB == RW * 1024, "one piece per wave, tile and operand");
+  unsigned dma_ko, dma_vo;
+  {
+    const int row = wave * 16 + lane / 4, pc = lane % 4;
+    dma_ko = (unsigned)(row * RB + ((pc ^ ((row >> 2) & 3)) << 4));
+    dma_vo = (unsigned)(row * RB + ((pc ^ (((row >> 3) & 1) << 1)) << 4));
+  }
+  auto stage_dma = [&](int t, int buf) {  // tile t -> buffer buf (hipcc does not count these loads: the caller waits vmcnt(0))
+    const unsigned soff = (unsigned)t * TILE;
+    const unsigned lk = (unsigned)(__UINTPTR_TYPE__)Kbuf + buf * TILE + wave * 1024;
+    const unsigned lv = (unsigned)(__UINTPTR_TYPE__)Vbuf + buf * TILE + wave * 1024;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dma_ko), "s"(rk), "s"(soff) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lv), "v"(dma_vo), "s"(rv), "s"(soff) : "memory");
+  };
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) oacc[db][i] = 0.0f;
+  float l = 0.0f;  // this lane half's share of the row sum (of the unrounded probabilities)
+  // c = scale.log2(e) = f . 2^e, f in [0.5, 1): |f.q| <= 448 stays inside e4m3, 2^e and 2^(e-4) are the block scales of the hi / lo operands
+  const float c2 = p.scale * 1.4426950408889634f;
+  int ce;
+  const float cf = __builtin_frexpf(c2, &ce);
+  const int sb_hi = 0x01010101 * (127 + ce), sb_lo = 0x01010101 * (127 + ce - 4);
+  // minus the reference of this row (log2 units: a stale row maximum - SHIFT) in all 16 registers of a tuple = the C operand of every
+  // score chain (+inf, i.e. reference -inf, until the first tile has set it)
+  f32x16 negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = INFINITY;
+  asm volatile("" : "+v"(negm));  // opaque: else hipcc re-materialises the splat in front of every MFMA
+
+  stage_dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // Q~ = (hi + lo / 16) . 2^e, once per block (this also retires the Q loads: hipcc otherwise drains vmcnt in front of every tile)
+  i32x8 qlo;
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(qf[n], false), b = __builtin_amdgcn_cvt_pk_f32_fp8(qf[n], true);
+    const float t0 = a[0] * cf, t1 = a[1] * cf, t2 = b[0] * cf, t3 = b[1] * cf;
+    int hi = 0, lo = 0;
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(t0, t1, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(t2, t3, hi, true);
+    const f32x2 ha = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), hb = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32((t0 - ha[0]) * 16.0f, (t1 - ha[1]) * 16.0f, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32((t2 - hb[0]) * 16.0f, (t3 - hb[1]) * 16.0f, lo, true);
+    qf[n] = hi;
+    qlo[n] = lo;
+  }
+  asm volatile("" : "+v"(qf), "+v"(qlo));
+  __syncthreads();
+
+  // scores of the tile in log2 units, plus C: s[kb][i] = c.S[q = r][key = kv0 + 32kb + (i & 3) + 8(i >> 2) + 4h] + cop[i], -inf where
+  // the key is not visible
+  auto scores = [&](auto bufc, f32x16 (&s)[2], const f32x16 cop, const int kv0) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    i32x8 kf[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const u32x4 a = lds_read_b128(kptr0 + buf * TILE + kb * 32 * RB), b = lds_read_b128(kptr1 + buf * TILE + kb * 32 * RB);
+      kf[kb] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {  // the two chains one after the other: a K fragment's registers are free before the next tuple is needed
+      s[kb] = mfma_f8_sb(kf[kb], qf, cop, sb_hi);
+      s[kb] = mfma_f8_sb(kf[kb], qlo, s[kb], sb_lo);
+    }
+    if ((CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk)) {  // tiles that cross the diagonal or the end of the sequence
+      int h4 = 4 * h;
+      asm volatile("" : "+v"(h4));  // pins the limit and the compares inside this branch
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        int lim = p.Nk - 1 - kv0 - 32 * kb - h4;
+        if (CAUSAL) lim = min(lim, qrow + coff - kv0 - 32 * kb - h4);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kb][i] = ((i & 3) + 8 * (i >> 2) > lim) ? -INFINITY : s[kb][i];
+      }
+    }
+  };
+
+  auto tile = [&](auto bufc, auto firstc, const int t) {
+    constexpr int buf = decltype(bufc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
+    const int kv0 = t * BN;
+    if (t + 1 < nT) stage_dma(t + 1, buf ^ 1);  // the next tile, in flight under this tile's arithmetic
+
+    int always = 1;
+    if constexpr (!CAUSAL) asm volatile("" : "+s"(always));  // (keeps the tile body a branch target: see fa_mfma16_kernel.hip)
+    const bool wave_active = CAUSAL ? (kv0 <= qw0 + WM - 1 + coff) : (always != 0);
+    if (wave_active) {
+      i32x8 pb;  // P^T as the B operand of the PV product: byte j of lane half h = element j = 16kb + i of the score tuples
+      float ls;
+      bool redo = FIRST;  // wave-uniform: renew the reference first (first tile: it is -inf)
+      for (;;) {
+        f32x16 s[2];
+        if (__builtin_expect(redo, 0)) {  // row maxima of the raw scores -> new reference; O and l follow
+          f32x16 zero;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+          scores(bufc, s, zero, kv0);
+          float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+          for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s[0][i]), s[1][i]);
+          float lo, hi;
+          half_pair(mx, lo, hi);
+          mx = fmaxf(lo, hi);
+          const float m_old = -negm[0];
+          const float m_new = fmaxf(m_old, mx - FA8_SHIFT);  // finite: every row sees key 0 of the first tile
+          const float alpha = __builtin_amdgcn_exp2f(m_old - m_new);
+          l *= alpha;
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[db][i] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) negm[i] = -m_new;
+          asm volatile("" : "+v"(negm));
+        }
+        __builtin_amdgcn_s_setprio(1);
+        scores(bufc, s, negm, kv0);
+        __builtin_amdgcn_s_setprio(0);
+        // P' = exp2(S'), its sum, and the packed e4m3 operand
+        float ls0 = 0.0f, ls1 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          s[0][i] = __builtin_amdgcn_exp2f(s[0][i]);
+          s[1][i] = __builtin_amdgcn_exp2f(s[1][i]);
+          ls0 = (i == 0) ? s[0][i] : ls0 + s[0][i];
+          ls1 = (i == 0) ? s[1][i] : ls1 + s[1][i];
+        }
+        ls = ls0 + ls1;
+        const bool stale = __builtin_amdgcn_ballot_w64(!(ls <= FA8_SUM_LIMIT)) != 0;  // wave-uniform (a NaN sum counts as stale)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(s[kb][4 * g + 0], s[kb][4 * g + 1], w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(s[kb][4 * g + 2], s[kb][4 * g + 3], w, true);
+            pb[4 * kb + g] = w;
+          }
+        if (__builtin_expect(!stale || redo, 1)) break;  // (after a renewal every P' <= 8: a second stale reading is inf / NaN input)
+        redo = true;
+      }
+      l += ls;
+      // ---- O^T += V^T.P^T: one MFMA per 32-wide d block, 64 keys deep
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        i32x8 vf;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            const i32x2 w = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                (__attribute__((address_space(3))) i32x2 *)(vptr[db] + buf * TILE + (32 * kb + 8 * g) * RB));
+            vf[4 * kb + g] = w[0];
+            vf[4 * kb + g + 1] = w[1];
+          }
+        oacc[db] = mfma_f8(vf, pb, oacc[db]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (t + 1 < nT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this tile have landed
+    __syncthreads();
+  };
+  tile(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+  for (int t = 1; t < nT; t += 2) {
+    tile(std::integral_constant<int, 1>{}, std::false_type{}, t);
+    if (t + 1 < nT) tile(std::integral_constant<int, 0>{}, std::false_type{}, t + 1);
+  }
+
+  // ---- epilogue: normalise, LSE, O tile (bf16) -> LDS -> coalesced 16-byte stores
+  lds_char *Ot = smem + wave * (WM * ORB);  // this wave's [32][D] bf16 tile (the K / V buffers are free since the last barrier)
+  {
+    float lo, hi;
+    half_pair(l, lo, hi);
+    l = lo + hi;
+  }
+  const float inv_l = __builtin_amdgcn_rcpf(l);
+  if (p.lse != nullptr && h == 0 && qrow < p.N) p.lse[(long long)bh * p.N + qrow] = (__builtin_amdgcn_logf(l) - negm[0]) * 0.6931471805599453f;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      // registers 4g4 .. 4g4+3 = d columns 32db + 8g4 + 4h + 0..3 of row r
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 e;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e[i] = (__bf16)(oacc[db][4 * g4 + i] * inv_l);
+      const int col_b = (32 * db + 8 * g4 + 4 * h) * 2;
+      const int ch = (col_b >> 4) ^ (r & (CPO - 1));
+      lds_write_b64(Ot + r * ORB + (ch << 4) + (col_b & 15), __builtin_bit_cast(u32x2, e));
+    }
+  __syncthreads();
+  {
+    __bf16 *Og = (__bf16 *)p.o + base;
+#pragma unroll
+    for (int it = 0; it < WM * CPO / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / CPO, ch = idx % CPO;
+      const u32x4 vv = lds_read_b128(Ot + row * ORB + ((ch ^ (row & (CPO - 1))) << 4));
+      if (qw0 + row < p.N) *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
+    }
+  }
+}
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(NTHREADS, FA8_OCC) void fwd_fp8_kernel(Params p) {
+  fwd_fp8_body<D, CAUSAL>(p);
+}
+
+bool fp8pv_supported(int dtype, int D) { return dtype == FA_DTYPE_FP8_E4M3 && D == 64; }
+
+template <int D, bool CAUSAL>
+static hipError_t launch8_one(const Params &p, hipStream_t s) {
+  const int nQ = (p.N + BM - 1) / BM;
+  const size_t smem = std::max((size_t)4 * BN * D, (size_t)BM * 2 * D);  // K / V double buffers; the epilogue's bf16 O tiles
+  auto kern = fwd_fp8_kernel<D, CAUSAL>;
+  Params pp = p;
+  pp.head_group = causal_head_group(p, D, 1);
+  set_block_divisors(pp, nQ, pp.head_group);
+  (void)hipGetLastError();  // do not report an older sticky error as this launch's
+  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
+  return hipGetLastError();
+}
+
+hipError_t launch_fp8pv(const Params &p, int dtype, hipStream_t s) {
+  if (p.D != 64 || dtype != FA_DTYPE_FP8_E4M3) return hipErrorInvalidValue;
+  return p.is_causal ? launch8_one<64, true>(p, s) : launch8_one<64, false>(p, s);
+}
+
+}  // namespace fa
