@@ -116,7 +116,9 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   // head_dim 64, 16-bit inputs, grids that fill the chip: the same workgroup on the 16x16x32 instruction with its row sums on the matrix
   // core -- config 3 +2 %, N >= 4096 non-causal / N >= 8192 causal +4.5..5.7 %; level at N = 2048, 1-2 % behind at N = 1024 (its
   // first tile pays a second score pass) (profiles/r04/ab_mfma16_ones_vs_adds.log)
-  if (fa::mfma16_supported(dtype, D) && N >= 2048) return FA_VARIANT_MFMA16;
+  // head_dim 128: from N = 8192 on (config 4 shard 1259-1300 -> 1323-1331 TFLOP/s, non-causal N = 8192 +4..5.7 %; level at N <= 4096;
+  // profiles/r04/ab_mfma16_d128*.log)
+  if (fa::mfma16_supported(dtype, D) && N >= (D == 64 ? 2048 : 8192)) return FA_VARIANT_MFMA16;
   // fp8 inputs, head_dim 64, grids that fill the chip: both products on the fp8 matrix pipe (config 5: 1215-1245 -> 1364-1461 TFLOP/s,
   // profiles/r04/ab_fp8pv_*.log). Its probabilities are e4m3 (include/fa_mi355.h, "fp8 probabilities"); FA_VARIANT_MFMA keeps them bf16
   if (fa::fp8pv_supported(dtype, D)) return FA_VARIANT_MFMA_FP8PV;
@@ -266,7 +268,7 @@ int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
     const bool small_grid = D == 64 && fa::splitkv_supported(dtype, D) && Nk > 64 && blocks128 <= 64;
     // the 16x16x32 kernel where fa_fwd's AUTO takes it: head_dim 64, 16-bit inputs, long key sequences on a grid that fills the chip
     variant = small_grid ? FA_VARIANT_MFMA_SPLITKV
-              : (fa::mfma16_supported(dtype, D) && Nk >= 2048 && blocks128 > 512) ? FA_VARIANT_MFMA16 : FA_VARIANT_MFMA;
+              : (fa::mfma16_supported(dtype, D) && Nk >= (D == 64 ? 2048 : 8192) && blocks128 > 512) ? FA_VARIANT_MFMA16 : FA_VARIANT_MFMA;
   }
   // the kernels that take the generalised problem (key/value heads, Nk): the 128-row kernel with / without its pre-scaled operand, its
   // 16x16x32 form, the split-KV kernel

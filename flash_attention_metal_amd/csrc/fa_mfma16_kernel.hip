@@ -32,10 +32,11 @@
 #define FA16_DEFER_THR 8.0f  // log2 units: P <= 2^8 between rescales
 #endif
 #ifndef FA16_LAK
-#define FA16_LAK 2  // K fragments are read this many fragments (each feeds two MFMAs) ahead of their use
+#define FA16_LAK (D == 128 ? 3 : 2)  // K fragments are read this many fragments (each feeds two MFMAs) ahead of their use (head_dim 128: 3,
+                                    // config 4 +1.5 % over 2, profiles/r04/ab_mfma16_d128_knobs.log)
 #endif
 #ifndef FA16_LAV
-#define FA16_LAV 2  // ... and V^T fragments
+#define FA16_LAV (D == 128 ? 3 : 2)  // ... and V^T fragments
 #endif
 #ifndef FA16_PRIO
 #define FA16_PRIO 1  // 1: wave priority raised around the MFMA clusters
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(NTHREADS, (D == 64 ? FA16_OCC : 2)) void fwd_mfma16
   fwd_mfma16_body<Tag, D, CAUSAL>(p);
 }
 
-bool mfma16_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D == 64; }
+bool mfma16_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128); }
 
 template <typename Tag, int D, bool CAUSAL>
 static hipError_t launch16_one(const Params &p, hipStream_t s) {
@@ -491,9 +492,13 @@ static hipError_t launch16_one(const Params &p, hipStream_t s) {
 }
 
 hipError_t launch_mfma16(const Params &p, int dtype, hipStream_t s) {
-  if (p.D != 64) return hipErrorInvalidValue;
-  if (dtype == FA_DTYPE_F16) return p.is_causal ? launch16_one<F16, 64, true>(p, s) : launch16_one<F16, 64, false>(p, s);
-  return p.is_causal ? launch16_one<BF16, 64, true>(p, s) : launch16_one<BF16, 64, false>(p, s);
+  auto go = [&](auto tag) -> hipError_t {
+    using Tag = decltype(tag);
+    if (p.D == 64) return p.is_causal ? launch16_one<Tag, 64, true>(p, s) : launch16_one<Tag, 64, false>(p, s);
+    if (p.D == 128) return p.is_causal ? launch16_one<Tag, 128, true>(p, s) : launch16_one<Tag, 128, false>(p, s);
+    return hipErrorInvalidValue;
+  };
+  return dtype == FA_DTYPE_F16 ? go(F16{}) : go(BF16{});
 }
 
 }  // namespace fa

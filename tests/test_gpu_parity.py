@@ -367,8 +367,8 @@ def test_generalised_forward_gqa_and_rectangular(fa, oracle_mod, dtype):
         # 16x16x32 form for long key sequences on large head_dim-64 grids; every kernel that takes the generalised problem also by name
         blocks = B * Hq * ((Nq + 127) // 128)
         small = D == 64 and Nk > 64 and blocks <= 64
-        auto = "mfma_splitkv" if small else "mfma16" if (D == 64 and Nk >= 2048 and blocks > 512) else "mfma"
-        for variant in ["auto", "mfma", "mfma_exact"] + (["mfma16", "mfma_splitkv"] if D == 64 else []):
+        auto = "mfma_splitkv" if small else "mfma16" if (D in (64, 128) and Nk >= (2048 if D == 64 else 8192) and blocks > 512) else "mfma"
+        for variant in ["auto", "mfma", "mfma_exact"] + (["mfma16"] if D in (64, 128) else []) + (["mfma_splitkv"] if D == 64 else []):
             name = auto if variant == "auto" else variant
             pre = {"mfma": int(D <= 128), "mfma16": 2}.get(name, 0)
             o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal, variant=variant)
@@ -582,7 +582,8 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
         (1, 80, 2047, 64, "bf16", True, "mfma"),           # ... N < 2048: the 32x32x16 kernel
         (1, 80, 2048, 64, "fp8", True, "mfma_fp8pv"),      # ... fp8 inputs have no 16x16x32 kernel: the all-fp8 kernel on grids that fill the chip
         (1, 64, 1024, 64, "bf16", True, "mfma"),           # ... and not at N = 1024
-        (1, 32, 4096, 128, "bf16", True, "mfma"),          # long head_dim-128 sequences: the 128-row kernel (round 2: paired-block)
+        (1, 32, 4096, 128, "bf16", True, "mfma"),          # head_dim-128 sequences below 8192: the 32x32x16 128-row kernel
+        (1, 16, 8192, 128, "bf16", True, "mfma16"),        # ... from 8192 on (config 4's shape family): its 16x16x32 form
         (1, 4, 300, 96, "bf16", True, "mfma"),             # head dims only the 128-row kernel has
         (1, 8, 1024, 64, "fp8", True, "mfma_splitkv"),
         (1, 40, 1024, 64, "fp8", True, "mfma_split2"),     # fp8, causal, 320 blocks, N >= 1024: the eight-wave form
@@ -692,13 +693,13 @@ def test_config5_full_fp8(fa, oracle_mod, variant):  # seqlen=8192, D=64, fp8 in
     assert np.concatenate(errs).max() < TOL_O["bf16"], (name, np.concatenate(errs).max())
 
 
-@pytest.mark.parametrize("variant", ["mfma_pp", "mfma"])
+@pytest.mark.parametrize("variant", ["mfma16", "mfma"])
 def test_config4_sharded_equals_unsharded_bit_for_bit(fa, oracle_mod, variant):
     # BASELINE configs[3] shards (batch, head) over 8 GPUs. The shards must be the SAME computation: here the
     # 8 shards of a reduced-batch config-4 tensor (B=8 -> 8 shards of 2 heads each, N=4096, D=128, bf16 causal) are
     # computed one by one on this GPU (as 8 ranks would, flash_attention_metal_amd.shard.shard_heads) and compared bit
     # for bit with the unsharded call. The kernels are named explicitly ("auto" on this reduced problem would pick by grid
-    # size); config 4 itself runs "mfma" on every rank.
+    # size); config 4 itself runs "mfma16" on every rank.
     import torch
 
     from flash_attention_metal_amd.shard import shard_heads
@@ -714,7 +715,7 @@ def test_config4_sharded_equals_unsharded_bit_for_bit(fa, oracle_mod, variant):
                                               is_causal=True, variant=variant)
         assert torch.equal(o_r[0], o_all.view(B * H, N, D)[lo:hi]) and torch.equal(l_r[0], l_all.view(B * H, N)[lo:hi])
     lib = fa.load_library()  # and the real config 4 resolves to the same kernel sharded or not
-    assert lib.fa_resolve_variant_for(2, 128, 8, 32, 16384, 1) == lib.fa_resolve_variant_for(2, 128, 1, 32, 16384, 1) == fa.VARIANTS["mfma"]
+    assert lib.fa_resolve_variant_for(2, 128, 8, 32, 16384, 1) == lib.fa_resolve_variant_for(2, 128, 1, 32, 16384, 1) == fa.VARIANTS["mfma16"]
     torch.cuda.synchronize()
 
 

@@ -1,8 +1,4 @@
 set -o pipefail
-mkdir -p gpurun_out/r4n
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/r4n/gpu_tests.log 2>&1; rc=$?; tail -4 gpurun_out/r4n/gpu_tests.log; grep -n "Error\|assert " gpurun_out/r4n/gpu_tests.log | head
-[ $rc -eq 0 ] || exit $rc
-./driver/fa_driver --iters 10 > gpurun_out/r4n/driver_full.log 2>&1 || { echo "driver failed"; tail -5 gpurun_out/r4n/driver_full.log; exit 1; }
-cp benchmark_results.csv benchmark_extended.csv gpurun_out/r4n/ 2>/dev/null
-grep -E "PASSED|FAILED" gpurun_out/r4n/driver_full.log | head -12; grep -E "^c[2-5]" gpurun_out/r4n/driver_full.log
-python3 bench.py --steps 20 --warmup 5 > gpurun_out/r4n/bench20.json 2> gpurun_out/r4n/bench20.err && head -c 700 gpurun_out/r4n/bench20.json && echo
+mkdir -p gpurun_out/r4p
+L="tools/ab/lib_d128.so:4 tools/ab/lib_d128.so:10"; for n in la3 la4 lak4 lav4; do L="$L tools/ab/lib_d_$n.so:10"; done
+python3 tools/ab.py $L --shapes c4,d128nc --rounds 8 --iters 10 2>&1 | grep -v amdgpu.ids | tr '|' '\n' > gpurun_out/r4p/ab_d128_knobs.log; cat gpurun_out/r4p/ab_d128_knobs.log
