@@ -67,7 +67,7 @@ int fa_supported(int dtype, int variant, int D) {
     case FA_VARIANT_TILED: return fa::tiled_supported(dtype, D);
     case FA_VARIANT_TILED_V2: return fa::tiled_v2_supported(dtype, D);
     case FA_VARIANT_MFMA: return fa::mfma_supported(dtype, D);
-    case FA_VARIANT_MFMA_PP: return fa::pp_supported(dtype, D);
+    case FA_VARIANT_MFMA_PP: return 0;  // retired in round 4 (tools/experiments/fa_fwd_pp_kernel.hip): the enum value stays reserved
     case FA_VARIANT_MFMA_SPLITKV: return fa::splitkv_supported(dtype, D);
     case FA_VARIANT_MFMA_SPLIT2: return fa::mfma_split2_supported(dtype, D);
     case FA_VARIANT_MFMA_EXACT: return fa::mfma_supported(dtype, D);
@@ -91,7 +91,7 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   if (v != FA_VARIANT_MFMA) return v;
   // (round 2 sent long head_dim-128 sequences to the paired-block kernel; since the 128-row kernel stages its tiles by
   // LDS-DMA it is 8-10 % ahead there too -- config 4 shard 1295 vs 1181 TFLOP/s, profiles/r03/ab_dma_late_and_d128_auto.log --
-  // and FA_VARIANT_MFMA_PP is reachable by name only)
+  // and round 4 retired FA_VARIANT_MFMA_PP: the kernel is kept under tools/experiments/)
   // small grids: fewer 128-row workgroups than a quarter of the CUs (or half, when each would walk >= 32 tiles):
   // split the keys of every 32-row block over the waves of a workgroup instead (config 2: 15.9 -> 10.6 us)
   const long long blocks128 = (long long)B * H * ((N + 127) / 128);
@@ -131,7 +131,6 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
   const char *tag = dtype == FA_DTYPE_F32 ? "float" : dtype == FA_DTYPE_F16 ? "fa::F16" : dtype == FA_DTYPE_BF16 ? "fa::BF16" : "fa::FP8";
   const char *c = is_causal ? "true" : "false";
   switch (v) {
-    case FA_VARIANT_MFMA_PP: snprintf(name, sizeof(name), "fa::fwd_pp_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_SPLITKV: snprintf(name, sizeof(name), "fa::fwd_splitkv_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_SPLIT2: snprintf(name, sizeof(name), "fa::fwd_mfma_split2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_H64S2: snprintf(name, sizeof(name), "fa::fwd_mfma_h64s2_kernel<%s, %d, %s>", tag, D, c); break;
@@ -206,7 +205,6 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
     case FA_VARIANT_NAIVE: e = fa::launch_naive(p, dtype, s); break;
     case FA_VARIANT_TILED: e = fa::launch_tiled(p, dtype, s); break;
     case FA_VARIANT_TILED_V2: e = fa::launch_tiled_v2(p, dtype, s); break;
-    case FA_VARIANT_MFMA_PP: e = fa::launch_pp(p, dtype, s); break;
     case FA_VARIANT_MFMA_SPLITKV: e = fa::launch_splitkv(p, dtype, s); break;
     case FA_VARIANT_MFMA_SPLIT2: e = fa::launch_mfma_split2(p, dtype, s); break;
     case FA_VARIANT_MFMA_H64S2: e = fa::launch_mfma_h64s2(p, dtype, s); break;

@@ -65,14 +65,12 @@ hipError_t launch_mfma16(const Params &p, int dtype, hipStream_t s);
 bool mfma16_supported(int dtype, int D);
 hipError_t launch_fp8pv(const Params &p, int dtype, hipStream_t s);
 bool fp8pv_supported(int dtype, int D);
-hipError_t launch_pp(const Params &p, int dtype, hipStream_t s);
 hipError_t launch_splitkv(const Params &p, int dtype, hipStream_t s);
 
 bool naive_supported(int dtype, int D);
 bool tiled_supported(int dtype, int D);
 bool tiled_v2_supported(int dtype, int D);
 bool mfma_supported(int dtype, int D);
-bool pp_supported(int dtype, int D);
 bool splitkv_supported(int dtype, int D);
 int splitkv_waves(int D, int Nk);
 bool bwd_supported(int dtype, int D);

@@ -54,8 +54,9 @@ enum fa_variant {
   FA_VARIANT_TILED = 2,  /* LDS-tiled scalar "V1"                  (kernels.metal:72-171)  */
   FA_VARIANT_TILED_V2 = 3, /* 128-bit loads, double-buffered K/V "V2" (kernels.metal:462-596) */
   FA_VARIANT_MFMA = 4,   /* matrix-core kernel "V3/V4"             (kernels.metal:177,600): 128 query rows per workgroup */
-  FA_VARIANT_MFMA_PP = 5, /* same operator, paired-block pipeline: 256 query rows per workgroup, one wave per SIMD, both
-                            32-row blocks of a wave share every K/V fragment (head_dim 128, long sequences) */
+  FA_VARIANT_MFMA_PP = 5, /* RETIRED in library version 400 (reserved: fa_supported() answers 0, fa_fwd FA_ERR_UNSUPPORTED). Rounds 2-3:
+                            the paired-block pipeline (256 query rows per workgroup, one wave per SIMD, asm-owned accumulators); the
+                            128-row kernels beat it on every shape since they stage by LDS-DMA. Source: tools/experiments/ */
   FA_VARIANT_MFMA_SPLITKV = 6, /* same operator for small grids: one 32-row query block per workgroup, its keys split over
                             2-8 waves and merged in LDS through the row LSE (short sequences / few heads) */
   FA_VARIANT_MFMA_SPLIT2 = 7, /* same operator for grids that fill part of the chip: the 128-row workgroup of MFMA with eight
@@ -94,7 +95,7 @@ enum fa_status {
  *  lse           device pointer to B*H*N floats, contiguous [B,H,N]; may be NULL
  *  N             sequence length (queries == keys); any N >= 1
  *  D             head dim: 32, 64, 96, 128 or 256 for FA_VARIANT_MFMA (fp8 inputs: 64, 128, 256), 64 or 128 for
- *                FA_VARIANT_MFMA_PP, <= 128 (multiple of 4) for the scalar variants
+ *                FA_VARIANT_MFMA16 / _SPLIT2, 64 for _H64S2 / _SPLITKV / _FP8PV, <= 128 (multiple of 4) for the scalar variants
  *  scale         softmax scale (> 0); the reference passes 1/sqrt(D) (main.mm:13)
  *  dtype/variant enums above
  *  hip_stream    hipStream_t on the current device, or NULL
@@ -150,7 +151,7 @@ int fa_fwd_ex(const void *q, const void *k, const void *v, void *o, float *lse,
               long long kv_batch_stride, long long kv_head_stride,
               int is_causal, int dtype, void *hip_stream);
 /* fa_fwd_ex with the kernel named by the caller: FA_VARIANT_AUTO (= fa_fwd_ex), FA_VARIANT_MFMA, FA_VARIANT_MFMA_EXACT (no pre-scaled
- * query operand), FA_VARIANT_MFMA16 (f16 / bf16, D = 64) or FA_VARIANT_MFMA_SPLITKV (D = 64, 128); any other variant: FA_ERR_UNSUPPORTED. */
+ * query operand), FA_VARIANT_MFMA16 (f16 / bf16, D = 64, 128) or FA_VARIANT_MFMA_SPLITKV (D = 64); any other variant: FA_ERR_UNSUPPORTED. */
 int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
                int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
                long long q_batch_stride, long long q_head_stride,

@@ -45,16 +45,19 @@ def test_version_and_names(fa):
 def test_support_table(fa):
     for d in (64, 128):
         assert fa.supported("bf16", "mfma", d) and fa.supported("f16", "mfma", d)
-        assert fa.supported("bf16", "mfma_pp", d) and fa.supported("fp8_e4m3", "mfma_pp", d)
-        assert not fa.supported("f32", "mfma", d) and not fa.supported("f32", "mfma_pp", d)
+        assert not fa.supported("bf16", "mfma_pp", d) and not fa.supported("fp8_e4m3", "mfma_pp", d)  # retired in version 400
+        assert fa.supported("bf16", "mfma16", d) and fa.supported("f16", "mfma16", d) and not fa.supported("fp8_e4m3", "mfma16", d)
+        assert not fa.supported("f32", "mfma", d) and not fa.supported("f32", "mfma16", d)
         assert fa.supported("fp8_e4m3", "mfma", d) and not fa.supported("fp8_e4m3", "tiled_v2", d)
         for v in ("naive", "tiled", "tiled_v2"):
             for t in ("f32", "f16", "bf16"):
                 assert fa.supported(t, v, d)
     for d in (32, 96, 256):  # scope row f3: the other head dims run on the 128-row matrix-core kernel
-        assert fa.supported("bf16", "mfma", d) and fa.supported("f16", "mfma", d) and not fa.supported("bf16", "mfma_pp", d)
+        assert fa.supported("bf16", "mfma", d) and fa.supported("f16", "mfma", d) and not fa.supported("bf16", "mfma16", d)
     assert fa.supported("fp8_e4m3", "mfma", 256) and not fa.supported("fp8_e4m3", "mfma", 32) and not fa.supported("fp8_e4m3", "mfma", 96)
     assert not fa.supported("bf16", "mfma", 48) and not fa.supported("bf16", "mfma", 512)
+    assert fa.supported("fp8_e4m3", "mfma_fp8pv", 64) and not fa.supported("fp8_e4m3", "mfma_fp8pv", 128) and not fa.supported("bf16", "mfma_fp8pv", 64)
+    assert fa.supported("bf16", "mfma_splitkv", 64) and not fa.supported("bf16", "mfma_splitkv", 128)  # head_dim 64 only since version 400
     lib = fa.load_library()
     assert lib.fa_resolve_variant(fa.DTYPES["bf16"], 64) == fa.VARIANTS["mfma"]
     assert lib.fa_resolve_variant(fa.DTYPES["bf16"], 96) == fa.VARIANTS["mfma"]

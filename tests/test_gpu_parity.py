@@ -23,8 +23,8 @@ pytestmark = pytest.mark.gpu
 
 TOL_O = {"f32": 2e-5, "f16": 1.5e-3, "bf16": 6e-3}
 TOL_LSE = {"f32": 2e-5, "f16": 1e-4, "bf16": 1e-4}
-# the matrix-core kernels: 128-row workgroups ("mfma"), paired-block pipeline ("mfma_pp"); "auto" picks by grid size
-MFMA_VARIANTS = ["mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2", "mfma16", "mfma_fp8pv"]
+# the matrix-core kernels by name; "auto" picks by grid size
+MFMA_VARIANTS = ["mfma", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2", "mfma16", "mfma_fp8pv"]
 
 
 def need(fa, dtype, variant, D):
@@ -176,9 +176,9 @@ def test_causal_row0_is_v0_bit_exact(fa, oracle_mod, dtype, variant):
     assert np.array_equal(o[:, :, 0], v[:, :, 0])  # softmax over one key: O[0] == V[0]
 
 
-@pytest.mark.parametrize("variant,dtype", [("mfma", "bf16"), ("mfma", "f16"), ("mfma_pp", "bf16"), ("mfma_pp", "f16"),
+@pytest.mark.parametrize("variant,dtype", [("mfma", "bf16"), ("mfma", "f16"), 
                                            ("mfma_splitkv", "bf16"), ("mfma_splitkv", "f16"), ("mfma_split2", "bf16"), ("mfma_split2", "f16"),
-                                           ("mfma_exact", "bf16"), ("mfma_h64s2", "bf16"), ("mfma_h64s2", "f16"), ("mfma16", "bf16"), ("mfma16", "f16"), ("mfma", "fp8"), ("mfma_pp", "fp8"), ("mfma_splitkv", "fp8"), ("mfma_split2", "fp8"), ("mfma_fp8pv", "fp8"),
+                                           ("mfma_exact", "bf16"), ("mfma_h64s2", "bf16"), ("mfma_h64s2", "f16"), ("mfma16", "bf16"), ("mfma16", "f16"), ("mfma", "fp8"), ("mfma_splitkv", "fp8"), ("mfma_split2", "fp8"), ("mfma_fp8pv", "fp8"),
                                            ("tiled_v2", "f32"), ("tiled", "f32"), ("naive", "f32")])
 def test_mask_index_probe_exact(fa, oracle_mod, variant, dtype):
     # Q = 0 -> uniform softmax; V[j,0] = delta(j,t): causal O[i,0] = 1/(i+1) for i >= t, EXACTLY 0 left of it.
@@ -218,7 +218,7 @@ def test_forced_rescale_branch(fa, oracle_mod, dtype, variant):
     # large-magnitude scores: exercises exp2 range and max tracking (scale folded in log2 domain)
     q2, k2, v2 = make_qkv(oracle_mod, 1, 1, 256, 64, dtype, amp=4.0)
     check(fa, oracle_mod, q2, k2, v2, dtype, True, variant, tol_scale=4.0)
-    # deferred-max kernels (mfma_pp): the row max creeps up tile after tile by less than the rescale
+    # deferred-max kernels: the row max creeps up tile after tile by less than the rescale
     # threshold (2^8), then jumps far above it: exercises both the deferred and the taken path, on every
     # row of one block and on a single row of another
     N2 = 1024
@@ -654,14 +654,14 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, varia
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_pp", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2", "mfma16"])
+@pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2", "mfma16"])
 def test_config2_full(fa, oracle_mod, variant):  # seqlen=1024, D=64, B=1, H=8, fp16, non-causal
     # BASELINE configs[1] names the "V2-style tiled kernel": variant tiled_v2 (kernels.metal:462-596) runs it at
     # full size in fp16; the matrix-core kernels are checked on the same tensors
     _full_size(fa, oracle_mod, 1, 8, 1024, 64, "f16", False, [(0, 0), (0, 7)], variant=variant)
 
 
-@pytest.mark.parametrize("variant", ["auto", "mfma", "mfma_pp", "mfma_exact", "mfma16"])
+@pytest.mark.parametrize("variant", ["auto", "mfma", "mfma_exact", "mfma16"])
 def test_config3_full(fa, oracle_mod, variant):  # seqlen=4096, D=64, B=4, H=16, bf16, causal
     _full_size(fa, oracle_mod, 4, 16, 4096, 64, "bf16", True, [(0, 0), (1, 5), (3, 15)], variant=variant)
 

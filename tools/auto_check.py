@@ -7,7 +7,7 @@ import torch
 import flash_attention_metal_amd as fa
 ap = argparse.ArgumentParser(); ap.add_argument("--tol", type=float, default=0.07); ap.add_argument("--rounds", type=int, default=5)
 a = ap.parse_args()
-VARS = ["auto", "mfma", "mfma_splitkv", "mfma_split2", "mfma_h64s2", "mfma_pp"]
+VARS = ["auto", "mfma", "mfma16", "mfma_splitkv", "mfma_split2", "mfma_h64s2", "mfma_fp8pv"]
 shapes = []
 for D in (64, 128):
     for dt in ("bf16", "fp8"):

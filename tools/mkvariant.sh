@@ -15,7 +15,6 @@ for f in fa_api fa_scalar_kernels fa_bwd_kernels; do
 done
 /opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_mfma_kernel.hip -o $out/obj_$name/fa_mfma_kernel.o &
 /opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_mfma16_kernel.hip -o $out/obj_$name/fa_mfma16_kernel.o &
-/opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_fwd_pp_kernel.hip -o $out/obj_$name/fa_fwd_pp_kernel.o &
 /opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_fwd_splitkv_kernel.hip -o $out/obj_$name/fa_fwd_splitkv_kernel.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/lib_$name.so $out/obj_$name/*.o
