@@ -16,11 +16,13 @@ from .ops import (  # noqa: F401
     ForwardPlan,
     algorithmic_bytes,
     algorithmic_flops,
+    decode_workspace_bytes,
     flash_attention_backward,
+    flash_attention_decode,
     flash_attention_forward,
     forward_kernel_name,
     supported,
 )
 from .shard import shard_heads  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.4.0"

@@ -284,6 +284,48 @@ int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
   return FA_OK;
 }
 
+int fa_fwd_decode_supported(int dtype, int D, int Hq, int Hkv, int Nq) {
+  return fa::decode_supported(dtype, D) && Hq >= 1 && Hkv >= 1 && Nq >= 1 && Hq % Hkv == 0 && (long long)(Hq / Hkv) * Nq <= 32;
+}
+long long fa_fwd_decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, int D) {
+  if (B < 1 || Hq < 1 || Hkv < 1 || Nq < 1 || Nk < 1 || (D != 64 && D != 128) || Hq % Hkv) return 0;
+  return fa::decode_workspace_bytes(B, Hq, Hkv, Nq, Nk, D);
+}
+int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *lse, int B, int Hq, int Hkv, int Nq, int Nk, int D,
+                  float scale, long long q_batch_stride, long long q_head_stride, long long kv_batch_stride, long long kv_head_stride,
+                  int is_causal, int dtype, void *workspace, long long workspace_bytes, void *hip_stream) {
+  g_err[0] = 0;
+  if (!q || !k || !v || !o || !workspace) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: null pointer");
+  if (B < 1 || Hq < 1 || Hkv < 1 || Nq < 1 || Nk < 1 || D < 1) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: sizes must be >= 1");
+  if (Hq % Hkv) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: Hq=%d must be a multiple of Hkv=%d", Hq, Hkv);
+  if (is_causal && Nk < Nq)
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_decode: causal needs Nk >= Nq (bottom-right alignment would leave empty rows)");
+  if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: scale=%g must be > 0", (double)scale);
+  if (!fa_fwd_decode_supported(dtype, D, Hq, Hkv, Nq))
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_decode: needs f16 / bf16, D = 64 | 128 and (Hq / Hkv) * Nq <= 32 packed query rows; got dtype=%s D=%d "
+                "Hq=%d Hkv=%d Nq=%d (use fa_fwd_ex)", fa_dtype_name(dtype), D, Hq, Hkv, Nq);
+  if (q_head_stride < (long long)Nq * D || kv_head_stride < (long long)Nk * D || (q_batch_stride % 8) || (q_head_stride % 8) ||
+      (kv_batch_stride % 8) || (kv_head_stride % 8) || q_batch_stride < 0 || kv_batch_stride < 0 ||
+      (Hq > 1 && B > 1 && q_batch_stride < q_head_stride) || (Hkv > 1 && B > 1 && kv_batch_stride < kv_head_stride))
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: bad strides");
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) & 15)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: tensors and workspace must be 16-byte aligned");
+  if ((double)(Nk + 128) * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: one head exceeds 4 GiB");
+  const long long need = fa::decode_workspace_bytes(B, Hq, Hkv, Nq, Nk, D);
+  if (workspace_bytes < need)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: workspace of %lld bytes, fa_fwd_decode_workspace_bytes() asks for %lld", workspace_bytes, need);
+  if ((long long)B * Hq * Nq > 0x7fffffffLL || (long long)B * Hkv * 256 > 0x7fffffffLL) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: grid too large");
+  fa::DecodeParams p;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse; p.ws = (float *)workspace;
+  p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
+  p.q_bs = q_batch_stride; p.q_hs = q_head_stride; p.kv_bs = kv_batch_stride; p.kv_hs = kv_head_stride;
+  p.is_causal = is_causal ? 1 : 0;
+  p.S = fa::decode_splits(B, Hkv, Nk, D);
+  const hipError_t e = fa::launch_decode(p, D, dtype, (hipStream_t)hip_stream);
+  if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_fwd_decode: launch failed: %s", hipGetErrorString(e));
+  return FA_OK;
+}
+
 long long fa_bwd_workspace_bytes(int B, int H, int N) { return (long long)B * H * N * 4; }
 int fa_bwd_supported(int dtype, int D) { return fa::bwd_supported(dtype, D); }
 double fa_bwd_algorithmic_flops(int B, int H, int N, int D, int is_causal) {

@@ -46,6 +46,19 @@ struct Params {
   FastDiv fd_h, fd_gq, fd_nq, fd_hg, fd_per;  // by H, H/Hkv, nq, hg, hg*nq
 };
 
+// one fa_fwd_decode call (csrc/fa_decode_kernel.hip)
+struct DecodeParams {
+  const void *q, *k, *v;
+  void *o;
+  float *lse;  // nullable
+  float *ws;   // workspace: per item [16 QT rows][D] partial O (unnormalised), then [16 QT rows][2] (m, l)
+  int B, Hq, Hkv, Nq, Nk;
+  float scale;
+  long long q_bs, q_hs, kv_bs, kv_hs;  // elements
+  int is_causal;
+  int S;  // key splits per (batch, key head)
+};
+
 // dtype tags
 struct F32 {};
 struct F16 {};
@@ -67,6 +80,10 @@ hipError_t launch_fp8pv(const Params &p, int dtype, hipStream_t s);
 bool fp8pv_supported(int dtype, int D);
 hipError_t launch_splitkv(const Params &p, int dtype, hipStream_t s);
 
+hipError_t launch_decode(const DecodeParams &p, int D, int dtype, hipStream_t s);
+bool decode_supported(int dtype, int D);
+int decode_splits(int B, int Hkv, int Nk, int D);
+long long decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, int D);
 bool naive_supported(int dtype, int D);
 bool tiled_supported(int dtype, int D);
 bool tiled_v2_supported(int dtype, int D);

@@ -182,6 +182,67 @@ def _forward_ex(lib, q, k, v, is_causal, scale, variant, return_lse, out, lse, s
     return out, lse
 
 
+def decode_workspace_bytes(B: int, Hq: int, Hkv: int, Nq: int, Nk: int, D: int) -> int:
+    return int(load_library().fa_fwd_decode_workspace_bytes(B, Hq, Hkv, Nq, Nk, D))
+
+
+def flash_attention_decode(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    is_causal: bool = False,
+    scale: Optional[float] = None,
+    return_lse: bool = True,
+    out: Optional[torch.Tensor] = None,
+    lse: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None,
+    stream: Optional[int] = None,
+) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Few query rows against a long key sequence (include/fa_mi355.h fa_fwd_decode): q [B,Hq,Nq,D], k/v [B,Hkv,Nk,D] with
+    (Hq / Hkv) * Nq <= 32, f16 / bf16, D = 64 | 128; the same operator as flash_attention_forward on these shapes, laid out for
+    the HBM roofline. `workspace`: a uint8 device tensor of at least decode_workspace_bytes(...) bytes (allocated here if None --
+    the C entry point itself allocates nothing)."""
+    lib = load_library()
+    if q.dim() != 4 or k.dim() != 4 or k.shape != v.shape:
+        raise ValueError("q [B,Hq,Nq,D], k / v [B,Hkv,Nk,D]")
+    B, Hq, Nq, D = q.shape
+    Bk, Hkv, Nk, Dk = k.shape
+    if Bk != B or Dk != D or Hq % Hkv:
+        raise ValueError(f"incompatible shapes q {tuple(q.shape)} k/v {tuple(k.shape)}")
+    if not (q.is_cuda and k.is_cuda and v.is_cuda):
+        raise RuntimeError("flash_attention_decode needs device tensors: there is no CPU path")
+    if q.dtype not in (torch.float16, torch.bfloat16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError(f"unsupported / mixed dtypes {q.dtype} {k.dtype} {v.dtype}")
+    qbs, qhs = _strides(q)
+    kbs, khs = _strides(k)
+    if _strides(v) != (kbs, khs):
+        raise ValueError("k and v must share batch/head strides")
+    if out is None:
+        out = torch.empty_strided((B, Hq, Nq, D), q.stride(), dtype=q.dtype, device=q.device)
+    elif not out.is_cuda or out.device != q.device or out.dtype != q.dtype or out.shape != q.shape or _strides(out) != (qbs, qhs):
+        raise ValueError("out must be a device tensor with q's shape/strides")
+    if return_lse and lse is None:
+        lse = torch.empty((B, Hq, Nq), dtype=torch.float32, device=q.device)
+    if lse is not None and (not lse.is_cuda or lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != B * Hq * Nq):
+        raise ValueError("lse must be contiguous fp32 [B,Hq,Nq] on q's device")
+    need = decode_workspace_bytes(B, Hq, Hkv, Nq, Nk, D)
+    if workspace is None:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    elif not workspace.is_cuda or workspace.device != q.device or workspace.dtype != torch.uint8 or not workspace.is_contiguous():
+        raise ValueError("workspace must be a contiguous uint8 device tensor")
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if stream is None:
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+    with torch.cuda.device(q.device):
+        st = lib.fa_fwd_decode(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+                               B, Hq, Hkv, Nq, Nk, D, float(scale), qbs, qhs, kbs, khs, int(bool(is_causal)), _TORCH2FA[q.dtype],
+                               workspace.data_ptr(), workspace.numel(), stream)
+    if st != 0:
+        raise FaError(st, lib.fa_last_error().decode())
+    return out, lse
+
+
 def flash_attention_backward(
     q: torch.Tensor,
     k: torch.Tensor,

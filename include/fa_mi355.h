@@ -159,6 +159,22 @@ int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
                int is_causal, int dtype, int variant, void *hip_stream);
 
 /*
+ * Few query rows against a long key sequence (decode steps, short chunks; scope row f3, not in the reference): the same operator as
+ * fa_fwd_ex for (Hq / Hkv) * Nq <= 32, f16 / bf16, D = 64 | 128, laid out for the HBM roofline instead of the matrix cores -- the query
+ * heads of a key/value head are packed into one row block (K and V are read once per key head), the keys are split over several
+ * work items per (batch, key head), and the partial results (unnormalised O, m, l per item) meet in `workspace`, caller-owned device
+ * memory of fa_fwd_decode_workspace_bytes() bytes, 16-byte aligned, contents irrelevant before and after the call; a second launch
+ * on the same stream combines them. Pre-scaled query operand as FA_VARIANT_MFMA ("LSE accuracy" above). Asynchronous, allocates nothing.
+ */
+int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *lse,
+                  int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
+                  long long q_batch_stride, long long q_head_stride,
+                  long long kv_batch_stride, long long kv_head_stride,
+                  int is_causal, int dtype, void *workspace, long long workspace_bytes, void *hip_stream);
+long long fa_fwd_decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, int D);
+int fa_fwd_decode_supported(int dtype, int D, int Hq, int Hkv, int Nq);
+
+/*
  * Backward of the operator (row f1 of the scope table): the reference binds it as
  * flash_attention_backward_kernel, /root/reference/kernels.metal:905-921, host side
  * /root/reference/main.mm:1015-1058:

@@ -12,12 +12,30 @@ for (B, Hq, Hkv, Nq, Nk, D) in shapes:
     q = torch.randn(B, Hq, Nq, D, device="cuda", dtype=torch.bfloat16)
     k = torch.randn(B, Hkv, Nk, D, device="cuda", dtype=torch.bfloat16)
     v = torch.randn_like(k)
-    for _ in range(5): fa.flash_attention_forward(q, k, v, is_causal=True)
+    lib = fa.load_library(); st = torch.cuda.current_stream().cuda_stream
+    o0 = torch.empty_like(q); lse0 = torch.empty(B, Hq, Nq, dtype=torch.float32, device="cuda")
+    xargs = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o0.data_ptr(), lse0.data_ptr(), B, Hq, Hkv, Nq, Nk, D, D ** -0.5, Hq * Nq * D, Nq * D,
+             Hkv * Nk * D, Nk * D, 1, 2, st)
+    for _ in range(5): assert lib.fa_fwd_ex(*xargs) == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(50): fa.flash_attention_forward(q, k, v, is_causal=True)
+    for _ in range(50): lib.fa_fwd_ex(*xargs)
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 50 * 1e3
     byts = 2 * B * Hkv * Nk * D * 2
-    print(f"B{B} Hq{Hq} Hkv{Hkv} Nq{Nq} Nk{Nk} D{D}: {us:8.1f} us   K+V {byts / 1e6:7.1f} MB  {byts / us / 1e6:.2f} TB/s", flush=True)
+    line = f"B{B} Hq{Hq} Hkv{Hkv} Nq{Nq} Nk{Nk} D{D}: fa_fwd_ex {us:8.1f} us {byts / us / 1e6:.2f} TB/s"
+    if (Hq // Hkv) * Nq <= 32:  # fa_fwd_decode (round 4): packed query heads, key splits, workspace + combine
+        ws = torch.empty(fa.decode_workspace_bytes(B, Hq, Hkv, Nq, Nk, D), dtype=torch.uint8, device="cuda")
+        o = torch.empty_like(q); lse = torch.empty(B, Hq, Nq, dtype=torch.float32, device="cuda")
+        lib = fa.load_library(); st = torch.cuda.current_stream().cuda_stream  # raw C-ABI calls: the Python wrapper's checks cost more than a short launch
+        args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, Hq, Hkv, Nq, Nk, D, D ** -0.5, Hq * Nq * D, Nq * D,
+                Hkv * Nk * D, Nk * D, 1, 2, ws.data_ptr(), ws.numel(), st)
+        for _ in range(5): assert lib.fa_fwd_decode(*args) == 0
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(50): lib.fa_fwd_decode(*args)
+        e1.record(); torch.cuda.synchronize()
+        us2 = e0.elapsed_time(e1) / 50 * 1e3
+        line += f" | fa_fwd_decode {us2:8.1f} us {byts / us2 / 1e6:.2f} TB/s ({us / us2:.1f}x)"
+    print(line + f"   K+V {byts / 1e6:7.1f} MB", flush=True)
