@@ -191,13 +191,13 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   for (int j = 0; j < 8; ++j) ones[j] = (elem)1.0f;
   if constexpr (ONES) asm volatile("" : "+v"(ones));
   const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
-  // minus the reference in the 4 registers of a tuple per query tile = the C operand of each score chain's first MFMA (+inf, i.e.
-  // reference -inf, until the first tile's rare path has set it)
+  // minus the reference in the 4 registers of a tuple per query tile = the C operand of each score chain's first MFMA. It starts at
+  // BIAS (ONES: an assumed row maximum of 0, see tile()) / at -inf (sums by v_add: the first tile sets it from the true maxima)
   f32x4 negm[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) negm[qt][i] = INFINITY;
+    for (int i = 0; i < 4; ++i) negm[qt][i] = ONES ? -BIAS : INFINITY;
     asm volatile("" : "+v"(negm[qt]));  // opaque: else hipcc re-materialises the splat in front of every MFMA
   }
 
@@ -309,14 +309,19 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
         for (int i = 0; i < 4; ++i) mx[qt] = fmaxf(mx[qt], s[k2][qt][i]);
   };
   // row maxima of the raw scores -> new reference: rescale O and the row sums, rewrite the C-operand tuples (first tile and rare path)
-  auto new_reference = [&](float (&mx)[2]) __attribute__((always_inline)) {
+  auto new_reference = [&](auto firstc, float (&mx)[2]) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(firstc)::value;  // first tile: O and the row sums are still zero, nothing to rescale
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float v = mx[qt];
       v = fmaxf(v, xlane(v, 16));
       v = fmaxf(v, xlane(v, 32));
       const float m_old = -negm[qt][0];
-      const float m_new = fmaxf(m_old, v + BIAS);  // finite: every row sees key 0 of the first tile
+      const float m_new = FIRST ? v + BIAS : fmaxf(m_old, v + BIAS);  // finite: every row sees key 0 of the first tile
+#pragma unroll
+      for (int i = 0; i < 4; ++i) negm[qt][i] = -m_new;
+      asm volatile("" : "+v"(negm[qt]));
+      if constexpr (FIRST) continue;
       const float alpha = __builtin_amdgcn_exp2f(m_old - m_new);
       if constexpr (ONES) {
 #pragma unroll
@@ -328,9 +333,6 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) oacc[dt][qt][i] *= alpha;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) negm[qt][i] = -m_new;
-      asm volatile("" : "+v"(negm[qt]));
     }
   };
   constexpr int G = (FA16_HALVES != 0) ? 2 : 1;  // key-tile groups of the hot pass: 1 = all 16 score MFMAs, then the softmax; 2 = per 32-key half
@@ -360,14 +362,18 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
     if (wave_active) {
       vec8 pf[2][2];  // B operands of the PV product: k-step kp, query tile qt
       float ls[2] = {0.0f, 0.0f};
-      bool redo = FIRST;  // wave-uniform: first the row maxima of the raw scores -> new reference (first tile: the reference is -inf;
-                          // a 16-key reference for it, 4 MFMAs instead of 16, was measured: no gain, profiles/r04/ab_mfma16_first_tile.log)
+      // redo (wave-uniform): first the row maxima of the raw scores -> new reference, then the hot pass. The FIRST tile starts without
+      // it (ONES): its reference is the constant BIAS, i.e. an assumed row maximum of 0 -- any finite reference is as good as the true
+      // maximum as long as no P' reaches 2 (the hot pass's own test) and the row sums do not vanish (tested once, behind the first
+      // tile's PV product: scores below -2^6 only) -- which saves every block a whole score pass (16 MFMAs, the maxima, their cross-lane
+      // steps). (A 16-key reference for the first tile, 4 MFMAs instead of 16, was measured: no gain, profiles/r04/ab_mfma16_first_tile.log.)
+      bool redo = FIRST && !ONES;
       for (;;) {
         if (__builtin_expect(redo, 0)) {
           float mx[2] = {-INFINITY, -INFINITY};
           max_group(bufc, K0A{}, std::integral_constant<int, KT / 2>{}, kv0, mx);
           max_group(bufc, K0B{}, std::integral_constant<int, KT / 2>{}, kv0, mx);
-          new_reference(mx);
+          new_reference(firstc, mx);
         }
 #if FA16_PRIO
         __builtin_amdgcn_s_setprio(1);
@@ -378,46 +384,66 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
         bool stale;
         if constexpr (ONES) stale = __builtin_amdgcn_ballot_w64((bits & 0x40004000u) != 0) != 0;
         else stale = __builtin_amdgcn_ballot_w64(fmaxf(ls[0], ls[1]) > sum_thr) != 0;
-        if (__builtin_expect(!stale || redo, 1)) break;  // (after a redo every P' <= 2^-BIAS: a second stale reading is inf / NaN input)
-        redo = true;
-      }
-      if constexpr (!ONES) {
-        l[0] += ls[0];
-        l[1] += ls[1];
-      }
-#if FA16_PRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
-      // ---- O^T += V^T.P^T, and (ONES) the row sums from a fifth d tile of ones
-      {
-        constexpr int NV = 2 * DT, LA = FA16_LAV;
-        s16x4 wlo[NV], whi[NV];
-        auto vread = [&](int j) {  // step j = (kp, dt)
-          const lds_char *vb = vptr[j % DT] + buf * TILE + (32 * (j / DT)) * RB;
-          wlo[j] = lds_read_tr16(vb);            // keys 32kp + 4g + 0..3       (k elements 0..3)
-          whi[j] = lds_read_tr16(vb + 16 * RB);  // keys 32kp + 16 + 4g + 0..3  (k elements 4..7)
-        };
-#pragma unroll
-        for (int j = 0; j < LA; ++j) vread(j);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const s16x8 v8 = __builtin_shufflevector(wlo[j], whi[j], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt) oacc[j % DT][qt] = M::mfma(__builtin_bit_cast(vec8, v8), pf[j / DT][qt], oacc[j % DT][qt]);
-          if (j + LA < NV) vread(j + LA);
-          if constexpr (ONES) {
-            if (j % DT == DT - 1) {
-#pragma unroll
-              for (int qt = 0; qt < 2; ++qt) lacc[qt] = M::mfma(ones, pf[j / DT][qt], lacc[qt]);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_expect(stale && !redo, 0)) {  // (after a redo every P' <= 2^-BIAS: a second stale reading is inf / NaN input)
+          redo = true;
+          continue;
         }
-      }
+        if constexpr (!ONES) {
+          l[0] += ls[0];
+          l[1] += ls[1];
+        }
 #if FA16_PRIO
-      __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(1);
 #endif
+        // ---- O^T += V^T.P^T, and (ONES) the row sums from a fifth d tile of ones
+        {
+          constexpr int NV = 2 * DT, LA = FA16_LAV;
+          s16x4 wlo[NV], whi[NV];
+          auto vread = [&](int j) {  // step j = (kp, dt)
+            const lds_char *vb = vptr[j % DT] + buf * TILE + (32 * (j / DT)) * RB;
+            wlo[j] = lds_read_tr16(vb);            // keys 32kp + 4g + 0..3       (k elements 0..3)
+            whi[j] = lds_read_tr16(vb + 16 * RB);  // keys 32kp + 16 + 4g + 0..3  (k elements 4..7)
+          };
+#pragma unroll
+          for (int j = 0; j < LA; ++j) vread(j);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NV; ++j) {
+            const s16x8 v8 = __builtin_shufflevector(wlo[j], whi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) oacc[j % DT][qt] = M::mfma(__builtin_bit_cast(vec8, v8), pf[j / DT][qt], oacc[j % DT][qt]);
+            if (j + LA < NV) vread(j + LA);
+            if constexpr (ONES) {
+              if (j % DT == DT - 1) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) lacc[qt] = M::mfma(ones, pf[j / DT][qt], lacc[qt]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#if FA16_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if constexpr (FIRST && ONES) {
+          // the assumed reference was too HIGH for some row (every score of its first 64 keys below about -2^6: sums under 2^-64):
+          // start the tile over with the true maxima (O and the row sums hold nothing of weight: cleared)
+          if (__builtin_expect(!redo && __builtin_amdgcn_ballot_w64(fminf(lacc[0][0], lacc[1][0]) < 0x1p-64f) != 0, 0)) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) lacc[qt][i] = 0.0f;
+#pragma unroll
+              for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) oacc[dt][qt][i] = 0.0f;
+            }
+            redo = true;
+            continue;
+          }
+        }
+        break;
+      }
     }
     if (t + 1 < nT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this tile have landed
     __syncthreads();

@@ -252,6 +252,27 @@ def test_reference_max_overflow_path(fa, oracle_mod, dtype, D, variant):
 
 
 @pytest.mark.parametrize("variant", MFMA_VARIANTS)
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_strongly_negative_scores_from_the_first_tile_on(fa, oracle_mod, dtype, variant):
+    # The 16x16x32 kernel forms the FIRST tile's probabilities against an assumed row maximum of 0 and checks afterwards that no row's
+    # sum vanished (csrc/fa_mfma16_kernel.hip, tile()): rows whose every score is far below zero -- here around -40 ... -1400 in log2
+    # units, in all tiles or in the first tile only -- must come out like any other (every kernel runs the case).
+    need(fa, dtype, variant, 64)
+    B, H, N, D = 1, 3, 300, 64
+    rng = np.random.default_rng(77)
+    u = rng.standard_normal((1, 1, 1, D)).astype(np.float32)
+    u /= np.sqrt((u ** 2).sum())
+    for (alpha, beta, first_only) in ((4.0, 60.0, False), (12.0, 60.0, False), (30.0, 250.0, False), (12.0, 60.0, True)):
+        q = oracle_mod.round_to(alpha * u + 0.05 * rng.standard_normal((B, H, N, D)).astype(np.float32), dtype)
+        k = oracle_mod.round_to(-beta * u + 0.05 * rng.standard_normal((B, H, N, D)).astype(np.float32), dtype)
+        if first_only:  # keys 64.. are ordinary: the reference has to climb by hundreds of units at the second tile
+            k[:, :, 64:] = oracle_mod.round_to(rng.uniform(-1, 1, (B, H, N - 64, D)).astype(np.float32), dtype)
+        v = make_qkv(oracle_mod, B, H, N, D, dtype, seeds=(3, 4, 5))[2]
+        for causal in (False, True):
+            check(fa, oracle_mod, q, k, v, dtype, causal, variant, tol_scale=2.0)
+
+
+@pytest.mark.parametrize("variant", MFMA_VARIANTS)
 @pytest.mark.parametrize("D", [64, 128, 256])
 def test_reference_max_overflow_path_fp8(fa, oracle_mod, D, variant):
     # the same through the e4m3 score product: a few keys at the top of the e4m3 range (448) against rows of ~2
