@@ -1,5 +1,6 @@
-set -o pipefail
-mkdir -p gpurun_out/r4u
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "mfma16 or strongly_negative" > gpurun_out/r4u/tests.log 2>&1; rc=$?; tail -4 gpurun_out/r4u/tests.log; grep -n "Error\|assert " gpurun_out/r4u/tests.log | head
-python3 tools/ab.py tools/ab/lib_prev.so:4 tools/ab/lib_prev.so:10 tools/ab/lib_ft.so:10 --shapes c3,c2k,c1k,c512,nc4k,c16k,c4 --rounds 10 --iters 20 2>&1 | grep -v amdgpu.ids | tr '|' '\n' > gpurun_out/r4u/ab_first_tile.log; cat gpurun_out/r4u/ab_first_tile.log
-exit $rc
+#!/bin/bash
+set -e
+mkdir -p gpurun_out
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+timeout -k 10 400 python tools/ab.py tools/ab/lib_zz0.so:0 $L:0 tools/ab/lib_zz1.so:0 --shapes c1k,c2k,c3,c8k,c3x2,c3h,d128c2k,d128c4k,c5bf --rounds 6 --iters 20 > gpurun_out/ab_zz.log 2>&1
+cat gpurun_out/ab_zz.log

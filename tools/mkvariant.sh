@@ -10,7 +10,7 @@ src=$root/flash_attention_metal_amd/csrc
 out=$root/tools/ab
 mkdir -p $out/obj_$name
 common="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-division-by-zero"
-for f in fa_api fa_scalar_kernels fa_bwd_kernels; do
+for f in fa_api fa_scalar_kernels fa_bwd_kernels fa_fp8_kernel fa_decode_kernel; do
   [ -f $src/$f.o ] && cp $src/$f.o $out/obj_$name/$f.o
 done
 /opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_mfma_kernel.hip -o $out/obj_$name/fa_mfma_kernel.o &
@@ -18,4 +18,5 @@ done
 /opt/rocm/bin/hipcc $common -fno-honor-nans -fno-slp-vectorize $extra -c $src/fa_fwd_splitkv_kernel.hip -o $out/obj_$name/fa_fwd_splitkv_kernel.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/lib_$name.so $out/obj_$name/*.o
+rm -rf $out/obj_$name
 echo built $out/lib_$name.so
