@@ -351,8 +351,11 @@ static int bwd_impl(const char *fn, const void *q, const void *k, const void *v,
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)
     return fail(FA_ERR_INVALID_ARG, "%s: tensors must be 16-byte aligned", fn);
   if (!fa::bwd_supported(dtype, D))
-    return fail(FA_ERR_UNSUPPORTED, "%s: no kernel for dtype=%s D=%d (f16/bf16, D=64|128)", fn, fa_dtype_name(dtype), D);
+    return fail(FA_ERR_UNSUPPORTED, "%s: no kernel for dtype=%s D=%d (f16/bf16, D a multiple of 8 up to 128)", fn, fa_dtype_name(dtype), D);
   if ((double)(N > Nk ? N : Nk) * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "%s: one head exceeds 4 GiB", fn);
+  // head dims other than 64 / 128 run on zero-padded rows whose padding is fetched from offset 2^31 + ... (fa_bwd_kernels.hip, PAD)
+  if (D != 64 && D != 128 && (double)(N > Nk ? N : Nk) * D * 2 >= 2147483648.0)
+    return fail(FA_ERR_INVALID_ARG, "%s: one head exceeds 2 GiB (head dims other than 64 / 128)", fn);
   if (bs < 0 || kbs < 0) return fail(FA_ERR_INVALID_ARG, "%s: negative batch stride", fn);
   if ((long long)B * H > 0x7fffffffLL / (((N > Nk ? N : Nk) + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "%s: grid too large", fn);
   hipError_t e = fa::launch_bwd(q, k, v, o, d_o, lse, dq, dk, dv, (float *)workspace, B, H, Hkv, N, Nk, D, scale, bs, hs, kbs, khs,

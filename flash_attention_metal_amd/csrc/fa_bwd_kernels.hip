@@ -112,12 +112,28 @@ constexpr int bwd_sub_kv(int D) { return FA_BWD_SUB; }
   };                                                                                          \
   (void)BT; (void)BCPR; (void)BKS; (void)BDB; (void)BTILE; (void)STILE; (void)u_swz; (void)tr_off; (void)NTV; (void)RPP; (void)NPW; (void)dma_off
 
+// Head dims other than 64 / 128 (any multiple of 8 up to 128: 32, 96, ...) run the next larger instantiation on ZERO-PADDED rows
+// (PAD): rows keep their packed pitch of p.D elements in global memory; the LDS images and the register fragments have the
+// kernel's pitch, and every 16-byte chunk at or past column p.D is fetched from an offset outside the buffer descriptor's range,
+// which reads as zeros (register fragments and LDS-DMA alike). The padding columns then add 0 to every score and receive
+// gradients that are never stored. Same arithmetic per real column, (BD - D) / BD of the matrix work wasted (D = 96: a quarter).
+#define FA_BWD_PAD(PAD_)                                                                                      \
+  const int GRB = (PAD_) ? p.D * 2 : BRB; /* row bytes in global memory */                                    \
+  constexpr unsigned OOB = 0x80000000u;   /* past any head (bwd_impl keeps padded heads below 2 GiB) */       \
+  auto gcol = [&](int chunk) -> unsigned { return (!(PAD_) || chunk * 8 < p.D) ? (unsigned)chunk * 16 : OOB; }; \
+  auto dma_off_pad = [&](int wave_, int lane_) {                                                              \
+    const int row = wave_ * RPP + lane_ / BCPR, lc = (lane_ % BCPR) ^ u_swz(row);                             \
+    return (unsigned)(row * GRB) + gcol(lc);                                                                  \
+  };                                                                                                          \
+  (void)gcol; (void)dma_off_pad; (void)OOB
+
 // ---------------------------------------------------------------------------
 // dQ: workgroup = 128 query rows, wave = 32 rows (query on the lane, keys in the registers)
 // ---------------------------------------------------------------------------
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, bool PAD>
 __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams p) {
   FA_BWD_CONSTS(D, bwd_sub_dq(D));
+  FA_BWD_PAD(PAD);
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
   const long long base_kv = (long long)(bh / p.H) * p.kv_batch_stride + (long long)((bh % p.H) / (p.H / p.Hkv)) * p.kv_head_stride;
   const int q0 = qb * BM, qw0 = q0 + wave * WM, qrow = qw0 + r;
 
-  const unsigned head_bytes = (unsigned)p.N * BRB, kv_head_bytes = (unsigned)p.Nk * BRB;
+  const unsigned head_bytes = (unsigned)p.N * GRB, kv_head_bytes = (unsigned)p.Nk * GRB;
   const int coff = p.Nk - p.N;
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.q + base), 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base_kv), 0, kv_head_bytes, 0x00020000);
@@ -146,8 +162,8 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
   vec8 qf[BKS], dof[BKS];  // B operands: lane (r,h) holds row qrow, columns 16ks+8h..
 #pragma unroll
   for (int ks = 0; ks < BKS; ++ks) {
-    qf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * BRB + (2 * ks + h) * 16, 0, 0));
-    dof[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)qrow * BRB + (2 * ks + h) * 16, 0, 0));
+    qf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * GRB + gcol(2 * ks + h), 0, 0));
+    dof[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rdo, (unsigned)qrow * GRB + gcol(2 * ks + h), 0, 0));
   }
   // S' = K.Q~ - lse*log2e straight out of the matrix core (rows past N: -inf, p = 0); dP' = V.dO - delta likewise
   const bool qvalid = qrow < p.N;
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.o + base), 0, head_bytes, 0x00020000);
 #pragma unroll
     for (int ks = 0; ks < BKS; ++ks) {
-      const vec8 of = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(ro, (unsigned)qrow * BRB + (2 * ks + h) * 16, 0, 0));
+      const vec8 of = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(ro, (unsigned)qrow * GRB + gcol(2 * ks + h), 0, 0));
 #pragma unroll
       for (int j = 0; j < 8; ++j) dlt = __builtin_fmaf((float)of[j], (float)dof[ks][j], dlt);
     }
@@ -201,12 +217,13 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
   const int nT = (kv_end + BT - 1) / BT;
 
   constexpr bool DMA = FA_BWD_DMA != 0;
-  const unsigned dvo = dma_off(wave, lane);
+  static_assert(DMA || !PAD, "padded head dims are staged by LDS-DMA only");
+  const unsigned dvo = PAD ? dma_off_pad(wave, lane) : dma_off(wave, lane);
   // tile t -> buffer buf by LDS-DMA (hipcc does not count these loads: stage_write waits vmcnt(0))
   auto stage_dma = [&](int t, int buf) {
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-      const unsigned soff = (unsigned)t * STILE + j * 4096;
+      const unsigned soff = PAD ? (unsigned)(t * BT + j * 4 * RPP) * GRB : (unsigned)t * STILE + j * 4096;
       const unsigned lk = (unsigned)(__UINTPTR_TYPE__)KU + buf * STILE + (wave + 4 * j) * 1024;
       const unsigned lv = (unsigned)(__UINTPTR_TYPE__)VR + buf * STILE + (wave + 4 * j) * 1024;
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dvo), "s"(rk), "s"(soff) : "memory");
@@ -344,14 +361,15 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
   }
   // dQ^T[d][q]: lane (q = r, h) holds d = 32db + 8g4 + 4h + 0..3 -> one 16-byte store per group
   if (qvalid) {
-    float *dq = p.dq + base + (long long)qrow * BD;
+    float *dq = p.dq + base + (long long)qrow * (PAD ? p.D : BD);
 #pragma unroll
     for (int db = 0; db < BDB; ++db)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const float4 w = make_float4(dqacc[db][4 * g4] * p.scale, dqacc[db][4 * g4 + 1] * p.scale, dqacc[db][4 * g4 + 2] * p.scale,
                                      dqacc[db][4 * g4 + 3] * p.scale);
-        *reinterpret_cast<float4 *>(dq + 32 * db + 8 * g4 + 4 * h) = w;
+        const int d0 = 32 * db + 8 * g4 + 4 * h;
+        if (!PAD || d0 < p.D) *reinterpret_cast<float4 *>(dq + d0) = w;
       }
   }
 }
@@ -359,9 +377,10 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
 // ---------------------------------------------------------------------------
 // dK, dV: workgroup = 128 keys, wave = 32 keys (key on the lane, queries in the registers)
 // ---------------------------------------------------------------------------
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, bool PAD>
 __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParams p) {
   FA_BWD_CONSTS(D, bwd_sub_kv(D));
+  FA_BWD_PAD(PAD);
   using M = MT<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
   const long long base = (long long)bi * p.kv_batch_stride + (long long)hk * p.kv_head_stride;  // K, V, dK, dV
   const int k0 = kvb * BM, kw0 = k0 + wave * WM, krow = kw0 + r;
 
-  const unsigned head_bytes = (unsigned)p.N * BRB, kv_head_bytes = (unsigned)p.Nk * BRB;
+  const unsigned head_bytes = (unsigned)p.N * GRB, kv_head_bytes = (unsigned)p.Nk * GRB;
   const int coff = p.Nk - p.N;
   __amdgpu_buffer_rsrc_t rq, rdo;  // of the query head being visited (set_head)
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const elem *)p.k + base), 0, kv_head_bytes, 0x00020000);
@@ -391,8 +410,8 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
   vec8 kf[BKS], vf[BKS];  // B operands: lane (r,h) holds key row krow, columns 16ks+8h..
 #pragma unroll
   for (int ks = 0; ks < BKS; ++ks) {
-    kf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)krow * BRB + (2 * ks + h) * 16, 0, 0));
-    vf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)krow * BRB + (2 * ks + h) * 16, 0, 0));
+    kf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rk, (unsigned)krow * GRB + gcol(2 * ks + h), 0, 0));
+    vf[ks] = __builtin_bit_cast(vec8, __builtin_amdgcn_raw_buffer_load_b128(rv, (unsigned)krow * GRB + gcol(2 * ks + h), 0, 0));
   }
   const float c2 = p.scale * LOG2E;
 
@@ -440,12 +459,13 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
     row_src = (__builtin_amdgcn_readfirstlane(tid) < BT ? p.lse : p.delta) + (long long)(bi * p.H + hq) * p.N;
   };
   constexpr bool DMA = FA_BWD_DMA != 0;
-  const unsigned dvo = dma_off(wave, lane);
+  static_assert(DMA || !PAD, "padded head dims are staged by LDS-DMA only");
+  const unsigned dvo = PAD ? dma_off_pad(wave, lane) : dma_off(wave, lane);
   auto stage_load = [&](int t, int buf) {
     if constexpr (DMA) {  // (hipcc does not count these loads: stage_write waits vmcnt(0))
 #pragma unroll
       for (int j = 0; j < NPW; ++j) {
-        const unsigned soff = (unsigned)t * STILE + j * 4096;
+        const unsigned soff = PAD ? (unsigned)(t * BT + j * 4 * RPP) * GRB : (unsigned)t * STILE + j * 4096;
         const unsigned lq = (unsigned)(__UINTPTR_TYPE__)QU + buf * STILE + (wave + 4 * j) * 1024;
         const unsigned lo = (unsigned)(__UINTPTR_TYPE__)OU + buf * STILE + (wave + 4 * j) * 1024;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lq), "v"(dvo), "s"(rq), "s"(soff) : "memory");
@@ -629,12 +649,13 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
   }
   }  // query heads of the group
   if (krow < p.Nk) {
-    float *dk = p.dk + base + (long long)krow * BD, *dv = p.dv + base + (long long)krow * BD;
+    float *dk = p.dk + base + (long long)krow * (PAD ? p.D : BD), *dv = p.dv + base + (long long)krow * (PAD ? p.D : BD);
 #pragma unroll
     for (int db = 0; db < BDB; ++db)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int d0 = 32 * db + 8 * g4 + 4 * h;
+        if (PAD && d0 >= p.D) continue;
         *reinterpret_cast<float4 *>(dk + d0) = make_float4(dkacc[db][4 * g4] * p.scale, dkacc[db][4 * g4 + 1] * p.scale, dkacc[db][4 * g4 + 2] * p.scale,
                                                              dkacc[db][4 * g4 + 3] * p.scale);
         *reinterpret_cast<float4 *>(dv + d0) = make_float4(dvacc[db][4 * g4], dvacc[db][4 * g4 + 1], dvacc[db][4 * g4 + 2], dvacc[db][4 * g4 + 3]);
@@ -643,15 +664,15 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
 }
 
 // ---------------------------------------------------------------------------
-bool bwd_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128); }
+bool bwd_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 128 && D % 8 == 0; }
 
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, bool PAD>
 static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
   constexpr int BTILE = BN * D * 2;
   const int nBq = (p.N + BM - 1) / BM, nBk = (p.Nk + BM - 1) / BM;
   const size_t smem_dq = 4 * bwd_sub_dq(D) * BTILE, smem_kv = 4 * bwd_sub_kv(D) * BTILE + 2 * 2 * bwd_sub_kv(D) * BN * 4;
-  auto kq = bwd_dq_kernel<Tag, D, CAUSAL>;
-  auto kk = bwd_dkdv_kernel<Tag, D, CAUSAL>;
+  auto kq = bwd_dq_kernel<Tag, D, CAUSAL, PAD>;
+  auto kk = bwd_dkdv_kernel<Tag, D, CAUSAL, PAD>;
   hipError_t e = hipSuccess;
   if (smem_kv > 48 * 1024) e = set_dyn_lds_once((const void *)kk, (int)smem_kv);
   if (e != hipSuccess) return e;
@@ -667,8 +688,10 @@ static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {
 
 template <typename Tag>
 static hipError_t launch_bwd_dt(const BwdParams &p, hipStream_t s) {
-  if (p.D == 64) return p.is_causal ? launch_bwd_one<Tag, 64, true>(p, s) : launch_bwd_one<Tag, 64, false>(p, s);
-  return p.is_causal ? launch_bwd_one<Tag, 128, true>(p, s) : launch_bwd_one<Tag, 128, false>(p, s);
+  if (p.D == 64) return p.is_causal ? launch_bwd_one<Tag, 64, true, false>(p, s) : launch_bwd_one<Tag, 64, false, false>(p, s);
+  if (p.D == 128) return p.is_causal ? launch_bwd_one<Tag, 128, true, false>(p, s) : launch_bwd_one<Tag, 128, false, false>(p, s);
+  if (p.D < 64) return p.is_causal ? launch_bwd_one<Tag, 64, true, true>(p, s) : launch_bwd_one<Tag, 64, false, true>(p, s);
+  return p.is_causal ? launch_bwd_one<Tag, 128, true, true>(p, s) : launch_bwd_one<Tag, 128, false, true>(p, s);
 }
 
 hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,

@@ -9,7 +9,7 @@ registered for the CUDA/HIP device only -- there is deliberately no CPU implemen
 Autograd: the op carries a backward formula that saves (q, k, v, o, lse) and calls fa_bwd()
 (csrc/fa_bwd_kernels.hip; the math of /root/reference/kernels.metal:905-1265, which consumes the
 forward's LSE), through fa_bwd_ex: grouped-query heads (Hq % Hkv == 0) and Nq != Nk (causal: Nk >= Nq) are
-differentiated too. Shapes fa_bwd_ex has no kernel for (head dims other than 64 / 128, fp8 / fp32 inputs)
+differentiated too. Shapes fa_bwd_ex has no kernel for (head dims above 128 or not a multiple of 8, fp8 / fp32 inputs)
 raise instead of returning a silent zero gradient; so does a gradient flowing into the LSE output.
 """
 from __future__ import annotations
@@ -58,7 +58,7 @@ def _backward(ctx, grad_o, grad_lse):
     if not gqa_ok or q.dtype not in (torch.float16, torch.bfloat16) or \
             not load_library().fa_bwd_supported({torch.float16: 1, torch.bfloat16: 2}[q.dtype], D):
         raise FaError(-2, f"no backward kernel for q {tuple(q.shape)} k {tuple(k.shape)} {q.dtype} "
-                          "(fa_bwd_ex: f16 / bf16, Hq % Hkv == 0, causal needs Nk >= Nq, head_dim 64 or 128)")
+                          "(fa_bwd_ex: f16 / bf16, Hq % Hkv == 0, causal needs Nk >= Nq, head_dim a multiple of 8 up to 128)")
     go = grad_o.to(q.dtype)
     if go.stride() != q.stride():
         go = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device).copy_(go)

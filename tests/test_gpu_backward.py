@@ -43,7 +43,7 @@ def rel(a, ref):
     return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-4)
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_backward_vs_oracle(fa, oracle_mod, dtype, causal, D):
@@ -57,7 +57,7 @@ def test_backward_vs_oracle(fa, oracle_mod, dtype, causal, D):
             assert rel(g, ref) < TOL[dtype], (name, dtype, causal, B, H, N, rel(g, ref))
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128])
 @pytest.mark.parametrize("causal", [False, True])
 def test_backward_grouped_query_heads(fa, oracle_mod, causal, D):
     """fa_bwd_ex (scope rows f1 + f3): query head h reads key/value head h // G; dK / dV of a key head are the sums over its
@@ -122,7 +122,7 @@ def rect_reference(q, k, v, do, causal):
     return dq, dk.reshape(B, Hkv, G, Nk, D).sum(2), dv.reshape(B, Hkv, G, Nk, D).sum(2)
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128])
 @pytest.mark.parametrize("causal", [False, True])
 def test_backward_rectangular(fa, oracle_mod, causal, D):
     """fa_bwd_ex with Nq != Nk (the counterpart of fa_fwd_ex): cross-attention shapes, and bottom-right aligned causal masks."""
@@ -153,7 +153,7 @@ def test_backward_rectangular(fa, oracle_mod, causal, D):
         assert e.value.status == -2
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128])
 def test_backward_partial_last_key_tile_with_strongly_negative_scores(fa, oracle_mod, D):
     """Non-causal, Nk % 64 != 0, every score strongly negative (k = -8 q direction, f16): lse << 0, so a key slot past Nk -- whose
     K / V rows arrive as zeros -- would give P = exp(-lse) and overflow the cast of dS (inf x 0 = NaN in the whole dQ row) unless the
@@ -165,6 +165,7 @@ def test_backward_partial_last_key_tile_with_strongly_negative_scores(fa, oracle
         rng = np.random.default_rng(Nk)
         u = rng.standard_normal((B, Hkv, 1, D)).astype(np.float32)
         u /= np.sqrt((u ** 2).sum(-1, keepdims=True))
+        u *= np.float32((D / 64.0) ** 0.25)  # logits around -25 at every head dim
         q = oracle_mod.round_to(np.repeat(u, Hq // Hkv, axis=1) * 5.0 + 0.05 * rng.standard_normal((B, Hq, Nq, D)).astype(np.float32), dtype)
         k = oracle_mod.round_to(-8.0 * u * 5.0 + 0.05 * rng.standard_normal((B, Hkv, Nk, D)).astype(np.float32), dtype)
         v = oracle_mod.round_to(rng.uniform(-1, 1, (B, Hkv, Nk, D)).astype(np.float32), dtype)
@@ -179,7 +180,8 @@ def test_backward_partial_last_key_tile_with_strongly_negative_scores(fa, oracle
             assert np.isfinite(g).all(), (name, Nq, Nk, D)
             # (logits around -25: the rounding of the pre-scaled operands moves every score by ~1e-2, section "LSE accuracy" of the header;
             # the point here is a finite, sane gradient -- before the fix the whole dQ row was NaN)
-            assert rel(g, ref) < 0.1, (name, Nq, Nk, D, rel(g, ref))
+            # (head_dim 32: dS = P (dP - delta) cancels over fewer columns, measured 0.105 on dQ)
+            assert rel(g, ref) < (0.1 if D >= 64 else 0.2), (name, Nq, Nk, D, rel(g, ref))
 
 
 def test_backward_known_answers(fa, oracle_mod):
@@ -254,11 +256,36 @@ def test_backward_config3_shape_sampled_head(fa, oracle_mod):
 def test_backward_errors(fa):
     import torch
 
-    x = torch.zeros(1, 1, 128, 96, dtype=torch.bfloat16, device="cuda")  # head dims other than 64 / 128 have no backward kernel
     lse = torch.zeros(1, 1, 128, device="cuda")
-    with pytest.raises(fa.FaError) as e:
-        fa.flash_attention_backward(x, x, x, x, x, lse)
-    assert e.value.status == -2  # reported, not faked
+    for D in (256, 36, 136):  # the backward covers multiples of 8 up to 128 (the forward also has 256)
+        x = torch.zeros(1, 1, 128, D, dtype=torch.bfloat16, device="cuda")
+        with pytest.raises(fa.FaError) as e:
+            fa.flash_attention_backward(x, x, x, x, x, lse)
+        assert e.value.status == -2  # reported, not faked
+
+
+@pytest.mark.parametrize("D", [8, 16, 40, 48, 80, 112, 120])
+def test_backward_any_multiple_of_eight(fa, oracle_mod, D):
+    """Head dims other than 64 / 128 run the next larger kernel on zero-padded rows (fa_bwd_kernels.hip, PAD): any multiple of 8 up
+    to 128, causal and full, a ragged length with a partial last tile on both sides. The forward that supplies O and LSE here is the
+    fp64 oracle's (the forward kernels cover 32 / 64 / 96 / 128 / 256 only)."""
+    import torch
+
+    dtype = "bf16"
+    B, H, N = 1, 2, 203
+    q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype)
+    do = oracle_mod.round_to(oracle_mod.init_random(B * H * N * D, 45).reshape(B, H, N, D), dtype)
+    for causal in (False, True):
+        o64, lse64 = oracle_mod.attn_fwd_f64(q, k, v, causal)
+        qd, kd, vd, dod = (to_dev(x, dtype) for x in (q, k, v, do))
+        od = to_dev(oracle_mod.round_to(o64.astype(np.float32), dtype), dtype)
+        lsed = torch.from_numpy(lse64.astype(np.float32)).cuda()
+        dq, dk, dv = fa.flash_attention_backward(qd, kd, vd, od, dod, lsed, is_causal=causal)
+        torch.cuda.synchronize()
+        for name, g, ref in zip(("dq", "dk", "dv"), (dq, dk, dv), oracle_mod.attn_bwd_f64(q, k, v, do, causal)):
+            g = g.cpu().numpy()
+            assert np.isfinite(g).all(), (name, D, causal)
+            assert rel(g, ref) < TOL[dtype], (name, D, causal, rel(g, ref))
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
@@ -286,10 +313,19 @@ def test_torch_op_autograd_matches_sdpa(fa, oracle_mod, dtype, causal):
         err = (g.double() - g64).abs().max().item()
         assert err < tol * g64.abs().max().item(), (name, err, g64.abs().max().item())
     # shapes without a backward kernel raise instead of handing back a silent zero gradient
-    q96 = torch.zeros(1, 1, 64, 96, dtype=torch.bfloat16, device="cuda", requires_grad=True)
-    o96, _ = torch.ops.fa_mi355.attention_forward(q96, q96.detach(), q96.detach(), False, 0.0)
+    q256 = torch.zeros(1, 1, 64, 256, dtype=torch.bfloat16, device="cuda", requires_grad=True)  # the forward has head_dim 256, the backward not
+    o256, _ = torch.ops.fa_mi355.attention_forward(q256, q256.detach(), q256.detach(), False, 0.0)
     with pytest.raises(Exception):
-        o96.float().sum().backward()
+        o256.float().sum().backward()
+    # head_dim 96 (zero-padded rows of the 128 kernel) through autograd
+    q96, k96, v96 = (to_dev(x, dtype).requires_grad_(True) for x in make_qkv(oracle_mod, 1, 2, 130, 96, dtype))
+    o96, _ = torch.ops.fa_mi355.attention_forward(q96, k96, v96, causal, 0.0)
+    w96 = torch.randn(1, 2, 130, 96, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+    (o96.float() * w96).sum().backward()
+    r96 = [x.detach().double().requires_grad_(True) for x in (q96, k96, v96)]
+    (F.scaled_dot_product_attention(*r96, is_causal=causal) * w96.double()).sum().backward()
+    for g, g64 in zip((q96.grad, k96.grad, v96.grad), (x.grad for x in r96)):
+        assert (g.double() - g64).abs().max().item() < tol * g64.abs().max().item()
     o2, lse2 = torch.ops.fa_mi355.attention_forward(q, k, v, causal, 0.0)
     with pytest.raises(Exception):  # no gradient through the LSE output
         lse2.sum().backward()
