@@ -12,9 +12,14 @@
 //     lane i receives column i with row q in byte q; probed on the hardware: tools/probes/probe_tr8.hip)
 //   * e4m3 holds 2^-9 .. 448 with 3 mantissa bits: the probabilities are formed against a reference SHIFT = 3 (log2 units) BELOW the
 //     row maximum (P' = 8 P <= 8 when the reference is set; O and l carry the same factor, it cancels), which leaves 2^-13 of the row
-//     maximum above the flush-to-zero floor, and the reference is renewed when a lane's 32 probabilities add up to more than 448
-//     (then none of them can exceed the e4m3 range -- the conversion does not saturate: 480 -> NaN, probed). The price is the rounding
-//     of every probability to 3 mantissa bits: include/fa_mi355.h, "fp8 probabilities".
+//     maximum above the flush-to-zero floor. The conversion does not saturate (480 -> NaN, probed), and that is the staleness test:
+//   * the tile's row sums are a third MFMA, ones . P^T, into a fresh accumulator (every register of the tuple = the sum of row r's 64
+//     rounded probabilities; the V^T fragments are fetched under it): a probability past 448 makes that sum NaN, the wave renews its
+//     reference from the tile's maximum and repeats the tile (a backward branch, rare). No additions, no per-element test on the
+//     vector pipe -- the kernel is VALU-bound (90 % busy, the matrix pipe 31 %): config 5 1457 -> 1585 TFLOP/s, interleaved
+//     (profiles/r04/ab_fp8_ones_rowsums.log). FA8_ONES = 0 keeps the first form (31 additions per tile, renewal when a lane's 32
+//     probabilities add up to more than 448).
+//     The price of the e4m3 probabilities is their rounding to 3 mantissa bits, in O and now in l: include/fa_mi355.h, "fp8 probabilities".
 #include <stdlib.h>
 
 #include <algorithm>
@@ -27,6 +32,10 @@
 #ifndef FA8_SUM_LIMIT
 #define FA8_SUM_LIMIT 448.0f  // a lane's 32 probabilities of a tile may add up to this before the reference is renewed (e4m3 max)
 #endif
+#ifndef FA8_ONES
+#define FA8_ONES 1  // 1: the row sums come out of the matrix core (a third "d block" of ones against the e4m3 probabilities: l adds the
+#endif              // ROUNDED probabilities, the very weights of the PV product) and a stale reference shows as a NaN sum;
+                    // 0: round 4's first form, 31 additions per tile and a sum limit
 #ifndef FA8_OCC
 #define FA8_OCC 4
 #endif
@@ -126,7 +135,12 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[db][i] = 0.0f;
   float mref = -INFINITY;  // reference of this row, log2 units: (a stale) row maximum - SHIFT
-  float l = 0.0f;          // this lane half's share of the row sum (of the unrounded probabilities)
+  constexpr bool ONES = (FA8_ONES != 0);
+  float l = 0.0f;          // !ONES: this lane half's share of the row sum (of the unrounded probabilities); ONES: the whole row's sum
+  i32x8 ones8;             // e4m3 1.0 = 0x38 in every byte
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones8[i] = 0x38383838;
+  if constexpr (ONES) asm volatile("" : "+v"(ones8));  // (kept in registers: else re-materialised in front of every use)
   const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
 
   stage_dma(0, 0);
@@ -173,6 +187,20 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
     if (wave_active) {
       i32x8 pb;  // P^T as the B operand of the PV product: byte j of lane half h = element j = 16kb + i of the score tuples
       float ls;
+      i32x8 vf[DB];  // V^T fragments of the PV product (ONES: read under the row-sum MFMA, before its verdict)
+      auto read_vt = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+              const i32x2 w = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                  (__attribute__((address_space(3))) i32x2 *)(vptr[db] + buf * TILE + (32 * kb + 8 * g) * RB));
+              vf[db][4 * kb + g] = w[0];
+              vf[db][4 * kb + g + 1] = w[1];
+            }
+      };
       bool redo = FIRST;  // wave-uniform: renew the reference first (first tile: it is -inf)
       for (;;) {
         f32x16 s[2];
@@ -201,11 +229,12 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
         for (int i = 0; i < 16; ++i) {
           s[0][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[0][i], c2, -mref));
           s[1][i] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[1][i], c2, -mref));
-          ls0 = (i == 0) ? s[0][i] : ls0 + s[0][i];
-          ls1 = (i == 0) ? s[1][i] : ls1 + s[1][i];
+          if constexpr (!ONES) {
+            ls0 = (i == 0) ? s[0][i] : ls0 + s[0][i];
+            ls1 = (i == 0) ? s[1][i] : ls1 + s[1][i];
+          }
         }
         ls = ls0 + ls1;
-        const bool stale = __builtin_amdgcn_ballot_w64(!(ls <= FA8_SUM_LIMIT)) != 0;  // wave-uniform (a NaN sum counts as stale)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -215,26 +244,32 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
             w = __builtin_amdgcn_cvt_pk_fp8_f32(s[kb][4 * g + 2], s[kb][4 * g + 3], w, true);
             pb[4 * kb + g] = w;
           }
+        bool stale;  // wave-uniform
+        if constexpr (ONES) {
+          // the tile's row sums, ones . P^T: every register of the tuple = the sum of row r's 64 ROUNDED probabilities. A probability
+          // above e4m3's 448 has converted to NaN (v_cvt_pk_fp8_f32 does not saturate) and shows here as a NaN sum: the stale-reference test
+          f32x16 zero;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+          __builtin_amdgcn_s_setprio(1);
+          const f32x16 ts = mfma_f8(ones8, pb, zero);
+          read_vt();
+          __builtin_amdgcn_s_setprio(0);
+          ls = ts[0];
+          // (an integer test of the bit pattern: the file is compiled with -fno-honor-nans, under which `ls != ls` folds to false)
+          stale = __builtin_amdgcn_ballot_w64((__builtin_bit_cast(unsigned, ls) & 0x7fffffffu) > 0x7f800000u) != 0;
+        } else {
+          stale = __builtin_amdgcn_ballot_w64(!(ls <= FA8_SUM_LIMIT)) != 0;  // (a NaN sum counts as stale)
+        }
         if (__builtin_expect(!stale || redo, 1)) break;  // (after a renewal every P' <= 8: a second stale reading is inf / NaN input)
         redo = true;
       }
       l += ls;
       // ---- O^T += V^T.P^T: one MFMA per 32-wide d block, 64 keys deep
       __builtin_amdgcn_s_setprio(1);
+      if constexpr (!ONES) read_vt();
 #pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        i32x8 vf;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int g = 0; g < 4; g += 2) {
-            const i32x2 w = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-                (__attribute__((address_space(3))) i32x2 *)(vptr[db] + buf * TILE + (32 * kb + 8 * g) * RB));
-            vf[4 * kb + g] = w[0];
-            vf[4 * kb + g + 1] = w[1];
-          }
-        oacc[db] = mfma_f8(vf, pb, oacc[db]);
-      }
+      for (int db = 0; db < DB; ++db) oacc[db] = mfma_f8(vf[db], pb, oacc[db]);
       __builtin_amdgcn_s_setprio(0);
     }
     if (t + 1 < nT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this tile have landed
@@ -248,7 +283,7 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
 
   // ---- epilogue: normalise, LSE, O tile (bf16) -> LDS -> coalesced 16-byte stores
   lds_char *Ot = smem + wave * (WM * ORB);  // this wave's [32][D] bf16 tile (the K / V buffers are free since the last barrier)
-  {
+  if constexpr (!ONES) {
     float lo, hi;
     half_pair(l, lo, hi);
     l = lo + hi;

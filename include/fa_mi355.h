@@ -126,8 +126,12 @@ enum fa_status {
  * reached only by rows with one or two visible keys; the roundings of a row's weights are independent, so rows with many comparable
  * keys see a small fraction of it (measured on BASELINE config 5, U(-1,1) inputs: max 2.3e-2 over the first rows of the causal mask,
  * below the other kernels' 6e-3 on every row with more than 1024 keys). Weights below 2^-13 of the row's reference are flushed to
- * zero (e4m3's range). l and LSE add the UNROUNDED probabilities: LSE keeps the 1e-4 bound. FA_VARIANT_MFMA / FA_VARIANT_MFMA_EXACT
- * with fp8 inputs keep the probabilities in bf16 (the score product alone on the fp8 pipe).
+ * zero (e4m3's range). The row sum comes out of the matrix core as well (a block of ones against the e4m3 probabilities): l adds the
+ * ROUNDED weights -- O's weights add up to exactly 1 -- and
+ *     |lse - exact| <= ln(1 + 2^-4) < 2^-4,
+ * again reached only by rows with two or three comparable keys (measured on config 5: at most 4.1e-3 over rows with more than 64
+ * keys, 1e-3 typical). Callers that need the 1e-4 LSE with fp8 inputs name FA_VARIANT_MFMA / FA_VARIANT_MFMA_EXACT, which keep the
+ * probabilities in bf16 and add them in fp32 (the score product alone on the fp8 pipe).
  */
 int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse,
            int B, int H, int N, int D, float scale,

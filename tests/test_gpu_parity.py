@@ -17,7 +17,7 @@ Index logic (causal mask, tile skip, head/batch addressing) is checked bit-exact
 import numpy as np
 import pytest
 
-from util import LN2, effective_q, fp8pv_term, is_prescaled, lse_tol, make_qkv, o_tol, rowsum_term, run_op, to_dev
+from util import LN2, effective_q, fp8pv_lse_term, fp8pv_term, is_prescaled, lse_tol, make_qkv, o_tol, rowsum_term, run_op, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -127,7 +127,7 @@ def test_mfma_fp8_inputs_vs_oracle(fa, oracle_mod, D, causal, variant):
             o, lse = run_op(fa, q, k, v, "fp8", causal, variant)
             o64, l64 = oracle_mod.attn_fwd_f64(q, k, v, causal)
             assert np.abs(o - o64).max() < TOL_O["bf16"] * amp + fp8pv_term(variant, "fp8", v), (B, H, N, D, causal, amp, np.abs(o - o64).max())
-            assert np.abs(lse - l64).max() < 1e-4 * amp * amp
+            assert np.abs(lse - l64).max() < 1e-4 * amp * amp + fp8pv_lse_term(variant, "fp8")
 
 
 @pytest.mark.parametrize("variant", MFMA_VARIANTS)
@@ -143,7 +143,7 @@ def test_fp8_equals_bf16_kernel_on_same_values(fa, oracle_mod, variant):
             ob, lb = run_op(fa, q, k, v, "bf16", causal, variant)
         if variant == "mfma_fp8pv":  # probabilities rounded to e4m3: close to the bf16 kernel, not equal
             ob, lb = run_op(fa, q, k, v, "bf16", causal, "mfma_exact")
-            assert np.abs(l8 - lb).max() < 5e-5
+            assert np.abs(l8 - lb).max() < 5e-5 + fp8pv_lse_term(variant, "fp8")
             assert np.abs(o8 - ob).max() <= fp8pv_term(variant, "fp8", v) and np.sqrt(((o8 - ob) ** 2).mean()) < 0.1 * fp8pv_term(variant, "fp8", v)
         elif variant in ("mfma", "mfma_split2", "mfma_exact"):
             # these kernels (one body) multiply e4m3 by e4m3 on the scaled fp8 MFMA (64 head-dim elements per instruction): every
@@ -286,7 +286,7 @@ def test_reference_max_overflow_path_fp8(fa, oracle_mod, D, variant):
         o64, l64 = oracle_mod.attn_fwd_f64(q, k, v, causal)
         assert np.isfinite(o).all() and np.isfinite(lse).all()
         assert np.abs(o - o64).max() < TOL_O["bf16"] * 2.0 + fp8pv_term(variant, "fp8", v), (D, causal, np.abs(o - o64).max())
-        assert (np.abs(lse - l64) / np.maximum(1.0, np.abs(l64))).max() < 2e-5, (D, causal)  # = the 1e-4 absolute bar at LSE ~ 5
+        assert (np.abs(lse - l64) / np.maximum(1.0, np.abs(l64))).max() < 2e-5 + fp8pv_lse_term(variant, "fp8"), (D, causal)  # = the 1e-4 absolute bar at LSE ~ 5
 
 
 @pytest.mark.parametrize("variant", MFMA_VARIANTS)
@@ -357,7 +357,7 @@ def test_randomized_shapes(fa, oracle_mod, variant):
         tol = (TOL_O["f16"] if dtype == "f16" else TOL_O["bf16"]) + fp8pv_term(variant, dtype, v)
         pre = is_prescaled(fa, dtype, variant, B, H, N, D, causal)
         assert np.abs(o - o64).max() < tol, (B, H, N, D, dtype, causal, scale)
-        assert np.abs(lse - l64).max() < lse_tol(dtype, pre, q, k, scale), (B, H, N, D, dtype, causal, scale)
+        assert np.abs(lse - l64).max() < lse_tol(dtype, pre, q, k, scale) + fp8pv_lse_term(variant, dtype), (B, H, N, D, dtype, causal, scale)
         if pre:
             o64, l64 = oracle_mod.attn_fwd_f64(effective_q(oracle_mod, q, dtype, scale), k, v, causal, LN2)
             assert np.abs(o - o64).max() < tol and np.abs(lse - l64).max() < 1e-4 + rowsum_term(dtype, pre), (B, H, N, D, dtype, causal, scale)
@@ -627,7 +627,7 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
             pre = is_prescaled(fa, dtype, "auto", B, H, N, D, causal)
             tol = (TOL_O["f16"] if dtype == "f16" else TOL_O["bf16"]) + fp8pv_term(want, dtype, v[0, h])
             assert np.abs(o_a[0, h].float().cpu().numpy()[rows] - o64).max() < tol, (want, h)
-            assert np.abs(l_a[0, h].cpu().numpy()[rows] - l64).max() < lse_tol(dtype, pre, q[0, h], k[0, h]), (want, h)
+            assert np.abs(l_a[0, h].cpu().numpy()[rows] - l64).max() < lse_tol(dtype, pre, q[0, h], k[0, h]) + fp8pv_lse_term(want, dtype), (want, h)
 
 
 
@@ -708,7 +708,9 @@ def test_config5_full_fp8(fa, oracle_mod, variant):  # seqlen=8192, D=64, fp8 in
         o64, l64 = oracle_mod.attn_rows_f64(qh, kh, vh, rows, True)
         err = np.abs(o[b, h].float().cpu().numpy()[rows] - o64)
         assert err.max() < TOL_O["bf16"] + fp8pv_term(name, "fp8", vh), (name, err.max())
-        assert np.abs(lse[b, h].cpu().numpy()[rows] - l64).max() < TOL_LSE["bf16"]
+        lerr = np.abs(lse[b, h].cpu().numpy()[rows] - l64)
+        assert lerr.max() < TOL_LSE["bf16"] + fp8pv_lse_term(name, "fp8")
+        assert lerr[rows > 64].max() < TOL_LSE["bf16"] + 0.1 * fp8pv_lse_term(name, "fp8"), (name, lerr[rows > 64].max())  # long rows: the roundings average out (measured 4.1e-3)
         errs.append(err[rows > 1024])
     # long rows (more than 1024 comparable keys): the independent roundings of the e4m3 probabilities average out -- the bf16 bar holds
     assert np.concatenate(errs).max() < TOL_O["bf16"], (name, np.concatenate(errs).max())
