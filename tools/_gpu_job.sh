@@ -1,6 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-L=flash_attention_metal_amd/csrc/libfa_mi355.so
-timeout -k 10 300 python tools/ab.py $L:11 tools/ab/lib_hilo.so:11 --shapes c5,c5 --rounds 6 --iters 20 > gpurun_out/ab_fp8_hilo2.log 2>&1
-cat gpurun_out/ab_fp8_hilo2.log
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
+tail -3 gpurun_out/gpu_tests_full.log
+timeout -k 10 1500 bash tools/collect_profiles.sh r04b > gpurun_out/collect_r04b.log 2>&1 || { tail -30 gpurun_out/collect_r04b.log; exit 1; }
+tail -40 gpurun_out/collect_r04b.log
