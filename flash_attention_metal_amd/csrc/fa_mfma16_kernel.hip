@@ -49,6 +49,12 @@
 #ifndef FA16_HALVES
 #define FA16_HALVES 0  // 1: the hot pass works on one 32-key half at a time (16 live score registers instead of 32)
 #endif
+#ifndef FA16_BN128
+#define FA16_BN128 64  // keys per staged tile of the head_dim-128 instantiation (64: 64 KiB of LDS, two workgroups per CU; 32: 32 KiB)
+#endif
+#ifndef FA16_OCC128
+#define FA16_OCC128 2  // workgroups per CU the head_dim-128 kernel is compiled for (2: 256 registers, 3: 168)
+#endif
 #ifndef FA16_OCC
 #define FA16_OCC 4  // workgroups per CU the head_dim-64 kernel is compiled for (128 registers)
 #endif
@@ -82,8 +88,10 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   constexpr int CPR = D / 8;       // 16-byte chunks per row
   constexpr int KS = D / 32;       // 32-wide k-steps of the score product
   constexpr int DT = D / 16;       // 16-wide d tiles of O^T
-  constexpr int KT = BN / 16;      // 16-key tiles per KV tile
-  constexpr int TILE = BN * RB;    // bytes of one K (or V) tile
+  constexpr int BNK = (D == 128) ? FA16_BN128 : BN;  // keys per staged tile
+  constexpr int KT = BNK / 16;     // 16-key tiles per KV tile
+  constexpr int NKP = KT / 2;      // 32-key k-steps of the PV product
+  constexpr int TILE = BNK * RB;   // bytes of one K (or V) tile
   static_assert(D == 64 || D == 128, "head dims of the 16x16x32 kernel");
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
@@ -140,12 +148,12 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   }
 
   const int kv_end = CAUSAL ? min(p.Nk, q0 + BM + coff) : p.Nk;
-  const int nT = (kv_end + BN - 1) / BN;
+  const int nT = (kv_end + BNK - 1) / BNK;
 
   // ---- LDS-DMA staging: wave w moves the 1-KiB pieces w, w + 4, ... of each tile; inside a piece the LDS image is
   // lane-linear, so the chunk swizzle sits on the SOURCE address (one per-lane offset for K, one for V)
   constexpr int RPP = 1024 / RB;        // rows per piece
-  constexpr int NPW = (BN / RPP) / RW;  // pieces per wave, tile and operand
+  constexpr int NPW = (BNK / RPP) / RW;  // pieces per wave, tile and operand
   static_assert((RW * RPP) % 16 == 0, "the piece stride must keep the swizzle");
   unsigned dma_kvo, dma_vvo;
   {
@@ -233,7 +241,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   };
   // mask only on tiles that cross the diagonal or the end of the sequence (re-evaluated from scalars at every use: carried as a
   // bool across the passes of a tile hipcc kept it in a VGPR, v_cndmask + v_cmp per tile)
-  auto needs_mask = [&](const int kv0) __attribute__((always_inline)) { return (CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk); };
+  auto needs_mask = [&](const int kv0) __attribute__((always_inline)) { return (CAUSAL && (kv0 + BNK - 1 > qw0 + coff)) || (kv0 + BNK > p.Nk); };
   // S^T = K.Q^T + C for NKT key tiles from tile K0 on: s[k2][qt][i] = S[query 16qt + c][key kv0 + 16(K0 + k2) + 4g + i] + c_[qt];
   // K fragments read LA ahead of their use
   auto score_group = [&](auto bufc, auto k0c, auto &s, const f32x4 c0, const f32x4 c1) __attribute__((always_inline)) {
@@ -257,7 +265,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   };
   // pack the probabilities of NKT key tiles (from K0 on) into the PV operands pf[kp][qt] (k-step kp = two key tiles), rounded to
   // the input type; ONES: OR the packed words into `bits`
-  auto pack_group = [&](auto k0c, auto &s, vec8 (&pf)[2][2], unsigned &bits) __attribute__((always_inline)) {
+  auto pack_group = [&](auto k0c, auto &s, vec8 (&pf)[NKP][2], unsigned &bits) __attribute__((always_inline)) {
     constexpr int K0 = decltype(k0c)::value;
     constexpr int NKT = sizeof(s) / sizeof(s[0]);
 #pragma unroll
@@ -273,7 +281,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
       }
   };
   // the hot pass over NKT key tiles: P = exp2(S') -> pf (and `bits`, or the row sums ls)
-  auto hot_group = [&](auto bufc, auto k0c, auto nktc, const int kv0, vec8 (&pf)[2][2], unsigned &bits,
+  auto hot_group = [&](auto bufc, auto k0c, auto nktc, const int kv0, vec8 (&pf)[NKP][2], unsigned &bits,
                        float (&ls)[2]) __attribute__((always_inline)) {
     constexpr int NKT = decltype(nktc)::value;
     f32x4 s[NKT][2];
@@ -349,7 +357,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   auto tile = [&](auto bufc, auto firstc, const int t) {
     constexpr int buf = decltype(bufc)::value;
     constexpr bool FIRST = decltype(firstc)::value;
-    const int kv0 = t * BN;
+    const int kv0 = t * BNK;
     if (t + 1 < nT) stage_dma(t + 1, buf ^ 1);  // the next tile, in flight under this tile's MFMAs
 
     // whole-tile skip per wave (kernels.metal:682 with Br = 32)
@@ -360,7 +368,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
     if constexpr (!CAUSAL) asm volatile("" : "+s"(always));
     const bool wave_active = CAUSAL ? (kv0 <= qw0 + WM - 1 + coff) : (always != 0);
     if (wave_active) {
-      vec8 pf[2][2];  // B operands of the PV product: k-step kp, query tile qt
+      vec8 pf[NKP][2];  // B operands of the PV product: k-step kp, query tile qt
       float ls[2] = {0.0f, 0.0f};
       // redo (wave-uniform): first the row maxima of the raw scores -> new reference, then the hot pass. The FIRST tile starts without
       // it (ONES): its reference is the constant BIAS, i.e. an assumed row maximum of 0 -- any finite reference is as good as the true
@@ -397,7 +405,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
 #endif
         // ---- O^T += V^T.P^T, and (ONES) the row sums from a fifth d tile of ones
         {
-          constexpr int NV = 2 * DT, LA = FA16_LAV;
+          constexpr int NV = NKP * DT, LA = FA16_LAV;
           s16x4 wlo[NV], whi[NV];
           auto vread = [&](int j) {  // step j = (kp, dt)
             const lds_char *vb = vptr[j % DT] + buf * TILE + (32 * (j / DT)) * RB;
@@ -494,7 +502,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
 }
 
 template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA16_OCC : 2)) void fwd_mfma16_kernel(Params p) {
+__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA16_OCC : FA16_OCC128)) void fwd_mfma16_kernel(Params p) {
   fwd_mfma16_body<Tag, D, CAUSAL>(p);
 }
 
@@ -503,7 +511,7 @@ bool mfma16_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype
 template <typename Tag, int D, bool CAUSAL>
 static hipError_t launch16_one(const Params &p, hipStream_t s) {
   const int nQ = (p.N + BM - 1) / BM;
-  const size_t smem = 4 * (size_t)BN * D * 2;
+  const size_t smem = 4 * (size_t)(D == 128 ? FA16_BN128 : BN) * D * 2;
   auto kern = fwd_mfma16_kernel<Tag, D, CAUSAL>;
   if (smem > 48 * 1024) {
     hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);

@@ -1,7 +1,6 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
-tail -3 gpurun_out/gpu_tests_full.log
-timeout -k 10 1500 bash tools/collect_profiles.sh r04b > gpurun_out/collect_r04b.log 2>&1 || { tail -30 gpurun_out/collect_r04b.log; exit 1; }
-tail -40 gpurun_out/collect_r04b.log
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+timeout -k 10 500 python tools/ab.py $L:10 tools/ab/lib_bn32o3.so:10 tools/ab/lib_bn32o2.so:10 --shapes c4,d128c8k,d128c4k,d128nc --rounds 5 --iters 10 > gpurun_out/ab_d128_bn32.log 2>&1
+cat gpurun_out/ab_d128_bn32.log
