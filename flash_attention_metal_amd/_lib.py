@@ -22,6 +22,7 @@ SYMBOLS = {
     "fa_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_longlong, c_longlong, c_int, c_int, c_void_p]),
     "fa_bwd_ex": (c_int, [c_void_p] * 10 + [c_int] * 6 + [c_float] + [c_longlong] * 4 + [c_int, c_int, c_void_p]),
     "fa_bwd_workspace_bytes": (c_longlong, [c_int, c_int, c_int]),
+    "fa_bwd_workspace_bytes_ex": (c_longlong, [c_int] * 7 + [c_longlong] * 4),
     "fa_bwd_supported": (c_int, [c_int, c_int]),
     "fa_bwd_algorithmic_flops": (c_double, [c_int, c_int, c_int, c_int, c_int]),
     "fa_supported": (c_int, [c_int, c_int, c_int]),

@@ -327,6 +327,20 @@ int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *l
 }
 
 long long fa_bwd_workspace_bytes(int B, int H, int N) { return (long long)B * H * N * 4; }
+// elements from the first to one past the last of a [B,H,N,D] tensor under (batch, head) strides, rounded up to 16
+static long long extent16(int B, int H, int N, int D, long long bs, long long hs) {
+  const long long e = (long long)(B - 1) * bs + (long long)(H - 1) * hs + (long long)N * D;
+  return (e + 15) / 16 * 16;
+}
+static long long align256(long long x) { return (x + 255) / 256 * 256; }
+long long fa_bwd_workspace_bytes_ex(int dtype, int B, int Hq, int Hkv, int Nq, int Nk, int D, long long q_batch_stride,
+                                    long long q_head_stride, long long kv_batch_stride, long long kv_head_stride) {
+  long long bytes = align256((long long)B * Hq * Nq * 4);
+  if (dtype == FA_DTYPE_FP8_E4M3)  // bf16 copies of Q, K, V under their own strides
+    bytes += align256(2 * extent16(B, Hq, Nq, D, q_batch_stride, q_head_stride)) +
+             2 * align256(2 * extent16(B, Hkv, Nk, D, kv_batch_stride, kv_head_stride));
+  return bytes;
+}
 int fa_bwd_supported(int dtype, int D) { return fa::bwd_supported(dtype, D); }
 double fa_bwd_algorithmic_flops(int B, int H, int N, int D, int is_causal) {
   return 2.5 * fa_algorithmic_flops(B, H, N, D, is_causal);
@@ -344,20 +358,35 @@ static int bwd_impl(const char *fn, const void *q, const void *k, const void *v,
     return fail(FA_ERR_UNSUPPORTED, "%s: causal needs Nk >= Nq (bottom-right alignment would leave empty rows)", fn);
   if (Hkv < 1 || H % Hkv) return fail(FA_ERR_INVALID_ARG, "%s: Hkv=%d must divide Hq=%d", fn, Hkv, H);
   if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "%s: scale=%g must be > 0", fn, (double)scale);
-  if (hs < (long long)N * D || (H > 1 && bs < hs) || (bs % 8) || (hs % 8))
+  const int smul = dtype == FA_DTYPE_FP8_E4M3 ? 16 : 8;  // keeps every head 16-byte aligned
+  if (hs < (long long)N * D || (H > 1 && bs < hs) || (bs % smul) || (hs % smul))
     return fail(FA_ERR_INVALID_ARG, "%s: bad strides (batch %lld, head %lld)", fn, bs, hs);
-  if (khs < (long long)Nk * D || (Hkv > 1 && kbs < khs) || (kbs % 8) || (khs % 8))
+  if (khs < (long long)Nk * D || (Hkv > 1 && kbs < khs) || (kbs % smul) || (khs % smul))
     return fail(FA_ERR_INVALID_ARG, "%s: bad key/value strides (batch %lld, head %lld)", fn, kbs, khs);
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15)
     return fail(FA_ERR_INVALID_ARG, "%s: tensors must be 16-byte aligned", fn);
   if (!fa::bwd_supported(dtype, D))
-    return fail(FA_ERR_UNSUPPORTED, "%s: no kernel for dtype=%s D=%d (f16/bf16, D a multiple of 8 up to 128)", fn, fa_dtype_name(dtype), D);
+    return fail(FA_ERR_UNSUPPORTED, "%s: no kernel for dtype=%s D=%d (f16 / bf16 / fp8_e4m3, D a multiple of 8 up to 128)", fn, fa_dtype_name(dtype), D);
   if ((double)(N > Nk ? N : Nk) * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "%s: one head exceeds 4 GiB", fn);
   // head dims other than 64 / 128 run on zero-padded rows whose padding is fetched from offset 2^31 + ... (fa_bwd_kernels.hip, PAD)
   if (D != 64 && D != 128 && (double)(N > Nk ? N : Nk) * D * 2 >= 2147483648.0)
     return fail(FA_ERR_INVALID_ARG, "%s: one head exceeds 2 GiB (head dims other than 64 / 128)", fn);
   if (bs < 0 || kbs < 0) return fail(FA_ERR_INVALID_ARG, "%s: negative batch stride", fn);
   if ((long long)B * H > 0x7fffffffLL / (((N > Nk ? N : Nk) + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "%s: grid too large", fn);
+  if (dtype == FA_DTYPE_FP8_E4M3 && ((uintptr_t)workspace & 15)) return fail(FA_ERR_INVALID_ARG, "%s: workspace must be 16-byte aligned", fn);
+  if (dtype == FA_DTYPE_FP8_E4M3) {
+    // e4m3 Q, K, V (O and dO are bf16, as fa_fwd writes O for this dtype): widen them into the workspace behind delta
+    // (layout of fa_bwd_workspace_bytes_ex) and run the bf16 kernels on the copies
+    char *w = (char *)workspace + align256((long long)B * H * N * 4);
+    const long long eq = extent16(B, H, N, D, bs, hs), ek = extent16(B, Hkv, Nk, D, kbs, khs);
+    void *q16 = w, *k16 = w + align256(2 * eq), *v16 = w + align256(2 * eq) + align256(2 * ek);
+    hipError_t ec = fa::launch_widen_e4m3(q, q16, eq, (hipStream_t)hip_stream);
+    if (ec == hipSuccess) ec = fa::launch_widen_e4m3(k, k16, ek, (hipStream_t)hip_stream);
+    if (ec == hipSuccess) ec = fa::launch_widen_e4m3(v, v16, ek, (hipStream_t)hip_stream);
+    if (ec != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: launch failed: %s", fn, hipGetErrorString(ec));
+    q = q16; k = k16; v = v16;
+    dtype = FA_DTYPE_BF16;
+  }
   hipError_t e = fa::launch_bwd(q, k, v, o, d_o, lse, dq, dk, dv, (float *)workspace, B, H, Hkv, N, Nk, D, scale, bs, hs, kbs, khs,
                                 is_causal ? 1 : 0, dtype, (hipStream_t)hip_stream);
   if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "%s: launch failed: %s", fn, hipGetErrorString(e));

@@ -664,7 +664,45 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
 }
 
 // ---------------------------------------------------------------------------
-bool bwd_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 128 && D % 8 == 0; }
+bool bwd_supported(int dtype, int D) {
+  if (dtype == FA_DTYPE_FP8_E4M3) return D >= 16 && D <= 128 && D % 16 == 0;  // (rows of whole 16-byte chunks: the widening pass)
+  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 128 && D % 8 == 0;
+}
+
+// e4m3 inputs (the forward's config-5 family): Q, K, V are widened to bf16 -- exactly: every e4m3 value is a bf16 value -- into the
+// caller's workspace by one streaming pass, under their own element strides, and the bf16 kernels run on the copies (O and dO of that
+// family are bf16 already). 3 bytes of traffic per element against the backward's hundreds of FLOPs per element.
+__global__ __launch_bounds__(256) void widen_e4m3_kernel(const unsigned *in, unsigned *out, long long n16) {
+  // one thread = 16 elements: 16 bytes in, 32 bytes out
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+    const u32x4 w = *reinterpret_cast<const u32x4 *>(in + 4 * i);
+    u32x4 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], true);
+      // bf16 = the upper half of the fp32 pattern (exact here: an e4m3 value has 3 mantissa bits)
+      // (scalar temporaries on purpose: __builtin_bit_cast applied directly to a vector element expression reads element 0, see below)
+      const float a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+      const unsigned p0 = (__builtin_bit_cast(unsigned, a0) >> 16) | (__builtin_bit_cast(unsigned, a1) & 0xffff0000u);
+      const unsigned p1 = (__builtin_bit_cast(unsigned, b0) >> 16) | (__builtin_bit_cast(unsigned, b1) & 0xffff0000u);
+      if (j < 2) { lo[2 * j] = p0; lo[2 * j + 1] = p1; } else { hi[2 * (j - 2)] = p0; hi[2 * (j - 2) + 1] = p1; }
+    }
+    *reinterpret_cast<u32x4 *>(out + 8 * i) = lo;
+    *reinterpret_cast<u32x4 *>(out + 8 * i + 4) = hi;
+  }
+}
+
+// n elements (a multiple of 16, 16-byte aligned source) of e4m3 -> bf16
+hipError_t launch_widen_e4m3(const void *in, void *out, long long n, hipStream_t s) {
+  const long long n16 = n / 16;
+  long long blocks = (n16 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(widen_e4m3_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned *)in, (unsigned *)out, n16);
+  return hipGetLastError();
+}
 
 template <typename Tag, int D, bool CAUSAL, bool PAD>
 static hipError_t launch_bwd_one(const BwdParams &p, hipStream_t s) {

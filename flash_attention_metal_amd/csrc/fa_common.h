@@ -91,6 +91,7 @@ bool mfma_supported(int dtype, int D);
 bool splitkv_supported(int dtype, int D);
 int splitkv_waves(int D, int Nk);
 bool bwd_supported(int dtype, int D);
+hipError_t launch_widen_e4m3(const void *in, void *out, long long n, hipStream_t s);  // e4m3 -> bf16, n % 16 == 0
 hipError_t launch_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
                       float *dq, float *dk, float *dv, float *ws, int B, int H, int Hkv, int N, int Nk, int D, float scale,
                       long long bs, long long hs, long long kv_bs, long long kv_hs, int causal, int dtype, hipStream_t s);

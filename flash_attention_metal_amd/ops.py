@@ -262,8 +262,12 @@ def flash_attention_backward(
         raise ValueError("q, o, d_o must share one [B,Hq,N,D] shape and k, v one [B,Hkv,N,D] shape")
     if not all(t.is_cuda for t in (q, k, v, o, d_o, lse)):
         raise RuntimeError("flash_attention_backward needs device tensors: there is no CPU path")
-    if q.dtype not in (torch.float16, torch.bfloat16) or any(t.dtype != q.dtype for t in (k, v, o, d_o)):
-        raise ValueError("backward supports f16 / bf16 tensors of one dtype")
+    fp8 = q.dtype == torch.float8_e4m3fn
+    if fp8:  # e4m3 Q, K, V with the bf16 O the forward wrote for them (and a bf16 dO)
+        if any(t.dtype != q.dtype for t in (k, v)) or any(t.dtype != torch.bfloat16 for t in (o, d_o)):
+            raise ValueError("backward with e4m3 q needs e4m3 k, v and bf16 o, d_o")
+    elif q.dtype not in (torch.float16, torch.bfloat16) or any(t.dtype != q.dtype for t in (k, v, o, d_o)):
+        raise ValueError("backward supports f16 / bf16 tensors of one dtype (or e4m3 q, k, v with bf16 o, d_o)")
     B, H, N, D = q.shape
     Bk, Hkv, Nk, Dk = k.shape
     if (Bk, Dk) != (B, D) or H % Hkv:
@@ -276,7 +280,8 @@ def flash_attention_backward(
         raise ValueError("lse must be contiguous fp32 [B,H,N]")
     dq = torch.empty_strided((B, H, N, D), q.stride(), dtype=torch.float32, device=q.device)
     dk, dv = (torch.empty_strided((B, Hkv, Nk, D), k.stride(), dtype=torch.float32, device=q.device) for _ in range(2))
-    ws = torch.empty(lib.fa_bwd_workspace_bytes(B, H, N), dtype=torch.uint8, device=q.device)
+    ws = torch.empty(lib.fa_bwd_workspace_bytes_ex(_TORCH2FA[q.dtype], B, H, Hkv, N, Nk, D, bs, hs, kbs, khs), dtype=torch.uint8,
+                     device=q.device)
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     if stream is None:

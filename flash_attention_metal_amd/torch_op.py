@@ -9,7 +9,7 @@ registered for the CUDA/HIP device only -- there is deliberately no CPU implemen
 Autograd: the op carries a backward formula that saves (q, k, v, o, lse) and calls fa_bwd()
 (csrc/fa_bwd_kernels.hip; the math of /root/reference/kernels.metal:905-1265, which consumes the
 forward's LSE), through fa_bwd_ex: grouped-query heads (Hq % Hkv == 0) and Nq != Nk (causal: Nk >= Nq) are
-differentiated too. Shapes fa_bwd_ex has no kernel for (head dims above 128 or not a multiple of 8, fp8 / fp32 inputs)
+differentiated too. Shapes fa_bwd_ex has no kernel for (head dims above 128 or not a multiple of 8, fp32 inputs)
 raise instead of returning a silent zero gradient; so does a gradient flowing into the LSE output.
 """
 from __future__ import annotations
@@ -55,13 +55,13 @@ def _backward(ctx, grad_o, grad_lse):
         return None, None, None, None, None
     B, H, N, D = q.shape
     gqa_ok = k.dim() == 4 and (k.shape[0], k.shape[3]) == (B, D) and H % k.shape[1] == 0 and not (ctx.is_causal and k.shape[2] < N)
-    if not gqa_ok or q.dtype not in (torch.float16, torch.bfloat16) or \
-            not load_library().fa_bwd_supported({torch.float16: 1, torch.bfloat16: 2}[q.dtype], D):
+    fa_dt = {torch.float16: 1, torch.bfloat16: 2, getattr(torch, "float8_e4m3fn", None): 3}
+    if not gqa_ok or q.dtype not in fa_dt or not load_library().fa_bwd_supported(fa_dt[q.dtype], D):
         raise FaError(-2, f"no backward kernel for q {tuple(q.shape)} k {tuple(k.shape)} {q.dtype} "
-                          "(fa_bwd_ex: f16 / bf16, Hq % Hkv == 0, causal needs Nk >= Nq, head_dim a multiple of 8 up to 128)")
-    go = grad_o.to(q.dtype)
+                          "(fa_bwd_ex: f16 / bf16 / e4m3, Hq % Hkv == 0, causal needs Nk >= Nq, head_dim a multiple of 8 up to 128)")
+    go = grad_o.to(o.dtype)  # (e4m3 inputs: O and its gradient are bf16)
     if go.stride() != q.stride():
-        go = torch.empty_strided(q.shape, q.stride(), dtype=q.dtype, device=q.device).copy_(go)
+        go = torch.empty_strided(q.shape, q.stride(), dtype=o.dtype, device=q.device).copy_(go)
     dq, dk, dv = flash_attention_backward(q, k, v, o, go, lse, is_causal=ctx.is_causal,
                                           scale=(ctx.scale if ctx.scale > 0 else None))
     return dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype), None, None

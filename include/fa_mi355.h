@@ -189,7 +189,7 @@ int fa_fwd_decode_supported(int dtype, int D, int Hq, int Hkv, int Nq);
  * Here dq/dk/dv are WRITTEN (no zero-fill needed, no atomics, bitwise reproducible), laid out
  * like the inputs (element (b,h,i,d) at b*batch_stride + h*head_stride + i*D + d, fp32).
  * `workspace` is caller-owned scratch of fa_bwd_workspace_bytes(B,H,N) bytes (device memory).
- * dtype F16 or BF16; D = 64 (the reference's, kernels.metal:905-1265) or 128 natively, any other multiple of 8 up to 128 (32, 96, ...)
+ * dtype F16 or BF16 (FP8_E4M3: see fa_bwd_workspace_bytes_ex); D = 64 (the reference's, kernels.metal:905-1265) or 128 natively, any other multiple of 8 up to 128 (32, 96, ...)
  * through the next larger kernel on zero-padded rows (same results per real column; a head must then stay below 2 GiB). D = 256: none.
  */
 int fa_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
@@ -209,6 +209,12 @@ int fa_bwd_ex(const void *q, const void *k, const void *v, const void *o, const 
               long long q_batch_stride, long long q_head_stride, long long kv_batch_stride, long long kv_head_stride,
               int is_causal, int dtype, void *hip_stream);
 long long fa_bwd_workspace_bytes(int B, int H, int N);
+/* the same for any dtype and for fa_bwd_ex's shapes (fa_bwd: Hq = Hkv, Nq = Nk, one stride pair). dtype FA_DTYPE_FP8_E4M3 (Q, K, V
+ * e4m3 under their element strides, multiples of 16; O and d_o bf16 -- what fa_fwd writes for e4m3 inputs -- under the same element
+ * strides; D a multiple of 16): the backward first widens Q, K, V to bf16 -- exactly -- into this workspace, which is why it grows by two
+ * bytes per element of their extents, and then runs the bf16 kernels. For f16 / bf16 it returns fa_bwd_workspace_bytes(B,Hq,Nq) rounded up. */
+long long fa_bwd_workspace_bytes_ex(int dtype, int B, int Hq, int Hkv, int Nq, int Nk, int D, long long q_batch_stride,
+                                    long long q_head_stride, long long kv_batch_stride, long long kv_head_stride);
 int fa_bwd_supported(int dtype, int D);
 /* algorithmic FLOPs of one fa_bwd call: 2.5x the forward (five N x N x D products) */
 double fa_bwd_algorithmic_flops(int B, int H, int N, int D, int is_causal);

@@ -264,6 +264,56 @@ def test_backward_errors(fa):
         assert e.value.status == -2  # reported, not faked
 
 
+@pytest.mark.parametrize("D", [64, 128, 32, 96])
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_fp8_inputs(fa, oracle_mod, causal, D):
+    """e4m3 Q, K, V (BASELINE config 5's family) with the bf16 O the forward writes for them and a bf16 dO: fa_bwd_ex widens Q, K, V to
+    bf16 -- exactly -- into its workspace (fa_bwd_workspace_bytes_ex) and runs the bf16 kernels, so the bf16 bar applies against the
+    fp64 oracle on the e4m3 values. O and LSE come from the bf16-probability forward (variant mfma_exact: the all-fp8 forward AUTO takes
+    on large grids rounds its probabilities to e4m3 and carries 2^-4 on O and LSE, include/fa_mi355.h). Grouped heads and Nq != Nk too."""
+    import torch
+
+    for (B, Hq, Hkv, Nq, Nk) in ((1, 2, 2, 200, 200), (2, 4, 2, 129, 129), (1, 2, 1, 100, 260)):
+        q, _, _ = make_qkv(oracle_mod, B, Hq, Nq, D, "fp8", amp=2.0)
+        _, k, v = make_qkv(oracle_mod, B, Hkv, Nk, D, "fp8", amp=2.0)
+        do = oracle_mod.round_to(oracle_mod.init_random(B * Hq * Nq * D, 45).reshape(B, Hq, Nq, D), "bf16")
+        qd, kd, vd = (to_dev(x, "fp8") for x in (q, k, v))
+        dod = to_dev(do, "bf16")
+        if D in (64, 128):
+            o, lse = fa.flash_attention_forward(qd, kd, vd, is_causal=causal, variant="mfma_exact")
+        else:  # the forward has no e4m3 kernel for these head dims: O and LSE of the same values through the bf16 kernel (e4m3 -> bf16 is exact)
+            o, lse = fa.flash_attention_forward(to_dev(q, "bf16"), to_dev(k, "bf16"), to_dev(v, "bf16"), is_causal=causal, variant="mfma_exact")
+        assert o.dtype == torch.bfloat16
+        dq, dk, dv = fa.flash_attention_backward(qd, kd, vd, o, dod, lse, is_causal=causal)
+        torch.cuda.synchronize()
+        assert dq.shape == qd.shape and dk.shape == kd.shape and dq.dtype == torch.float32
+        for name, g, ref in zip(("dq", "dk", "dv"), (dq, dk, dv), rect_reference(q, k, v, do, causal)):
+            g = g.cpu().numpy()
+            assert np.isfinite(g).all(), (name, B, Hq, Hkv, Nq, Nk)
+            assert rel(g, ref) < TOL["bf16"], (name, causal, D, B, Hq, Hkv, Nq, Nk, rel(g, ref))
+    # bit-identical to the bf16 backward on the widened tensors (the widening is exact)
+    q, k, v = make_qkv(oracle_mod, 1, 2, 192, D, "fp8")
+    do = oracle_mod.round_to(oracle_mod.init_random(2 * 192 * D, 46).reshape(1, 2, 192, D), "bf16")
+    qb, kb, vb, dod = (to_dev(x, "bf16") for x in (q, k, v, do))
+    o, lse = fa.flash_attention_forward(qb, kb, vb, is_causal=causal)
+    g8 = fa.flash_attention_backward(to_dev(q, "fp8"), to_dev(k, "fp8"), to_dev(v, "fp8"), o, dod, lse, is_causal=causal)
+    gb = fa.flash_attention_backward(qb, kb, vb, o, dod, lse, is_causal=causal)
+    for a_, b_ in zip(g8, gb):
+        assert torch.equal(a_, b_)
+    # through torch.autograd (row f4): e4m3 leaves, bf16 O; the gradients come back in the leaves' dtype
+    import flash_attention_metal_amd.torch_op  # noqa: F401  (registers the op)
+
+    if D in (64, 128):
+        q8, k8, v8 = (to_dev(x, "fp8").requires_grad_(True) for x in (q, k, v))
+        o8, _ = torch.ops.fa_mi355.attention_forward(q8, k8, v8, causal, 0.0)
+        (o8.float() * dod.float()).sum().backward()
+        assert q8.grad is not None and q8.grad.dtype == q8.dtype and k8.grad.shape == k8.shape
+        o_ref, lse_ref = fa.flash_attention_forward(q8.detach(), k8.detach(), v8.detach(), is_causal=causal)
+        gq, gk, gv = fa.flash_attention_backward(q8.detach(), k8.detach(), v8.detach(), o_ref, dod, lse_ref, is_causal=causal)
+        for a_, b_ in zip((q8.grad, k8.grad, v8.grad), (gq, gk, gv)):
+            assert torch.equal(a_.float(), b_.to(a_.dtype).float())
+
+
 @pytest.mark.parametrize("D", [8, 16, 40, 48, 80, 112, 120])
 def test_backward_any_multiple_of_eight(fa, oracle_mod, D):
     """Head dims other than 64 / 128 run the next larger kernel on zero-padded rows (fa_bwd_kernels.hip, PAD): any multiple of 8 up
