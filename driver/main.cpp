@@ -418,6 +418,8 @@ static void run_configs(const Options &opt, std::ofstream &ext) {
       {"c4", 8, 32, 16384, 128, FA_DTYPE_BF16, true},  // 8-GPU config: on G GPUs, G/8 of its (b,h) slices
       {"c5", 4, 16, 8192, 64, FA_DTYPE_FP8_E4M3, true},  // fp8 in / fp32 accumulate / bf16 out (B,H assumed as c3); "auto": both products on the fp8 pipe
       {"c5_bf16p", 4, 16, 8192, 64, FA_DTYPE_FP8_E4M3, true, FA_VARIANT_MFMA},  // probabilities kept in bf16 (score product alone on the fp8 pipe)
+      {"c5_d128", 2, 16, 8192, 128, FA_DTYPE_FP8_E4M3, true},  // not a BASELINE config: config 5's dtype at head_dim 128 (same FLOPs), all-fp8 kernel
+      {"c5_d128_bf16p", 2, 16, 8192, 128, FA_DTYPE_FP8_E4M3, true, FA_VARIANT_MFMA},
   };
   for (const Config &c0 : cfgs) {
     for (int g = 1; g <= G; g *= 2) {

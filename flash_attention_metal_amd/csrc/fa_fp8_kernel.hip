@@ -1,4 +1,4 @@
-// fa_fp8_kernel.hip -- the operator for OCP e4m3 inputs with BOTH products on the fp8 matrix pipe (variant "mfma_fp8pv").
+// fa_fp8_kernel.hip -- the operator for OCP e4m3 inputs with BOTH products on the fp8 matrix pipe (variant "mfma_fp8pv"; head_dim 64, 128).
 //
 // BASELINE.json configs[4]: "fp8 Q/K/V with fp32 accumulate (CDNA4 fp8 MFMA)". Same math as the other matrix-core kernels (replaces
 // /root/reference/kernels.metal:600-883; mask kernels.metal:748, L = m + ln(l) kernels.metal:862-864). fa_mfma_kernel.hip runs only
@@ -20,6 +20,10 @@
 //     (profiles/r04/ab_fp8_ones_rowsums.log). FA8_ONES = 0 keeps the first form (31 additions per tile, renewal when a lane's 32
 //     probabilities add up to more than 448).
 //     The price of the e4m3 probabilities is their rounding to 3 mantissa bits, in O and now in l: include/fa_mi355.h, "fp8 probabilities".
+// Head dim 128 (the same kernel, template D): rows of 128 bytes, two 64-deep k-steps per score tuple, four PV products + the ones product
+// per tile, two LDS-DMA pieces per wave, tile and operand, its own chunk swizzles (two rows share a 64-bank line: K by (row >> 1) & 7;
+// V by chunk pairs so that the eight rows of a transposed read spread over the banks), 166 registers = three workgroups per CU:
+// 2 x 16 heads x 8192 causal 1410 (bf16 probabilities) -> 2021 TFLOP/s (profiles/r04/ab_fp8pv_head_dim_128.log).
 #include <stdlib.h>
 
 #include <algorithm>
@@ -39,6 +43,9 @@
 #ifndef FA8_OCC
 #define FA8_OCC 4
 #endif
+#ifndef FA8_OCC128
+#define FA8_OCC128 3  // workgroups per CU of the head_dim-128 instantiation (32 KiB of LDS; 168 registers)
+#endif
 
 namespace fa {
 
@@ -52,8 +59,10 @@ __device__ __forceinline__ f32x16 mfma_f8(i32x8 a, i32x8 b, f32x16 c) {
 
 template <int D, bool CAUSAL>
 __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
-  static_assert(D == 64, "head dim of the all-fp8 kernel");
+  static_assert(D == 64 || D == 128, "head dims of the all-fp8 kernel");
   constexpr int RW = BM / WM;     // waves
+  constexpr int KS = D / 64;      // 64-deep k-steps of the score product
+  constexpr int CPR = D / 16;     // 16-byte chunks of a K / V row
   constexpr int RB = D;           // row bytes of K / V (global and LDS)
   constexpr int ORB = 2 * D;      // row bytes of the bf16 O tile
   constexpr int TILE = BN * RB;   // bytes of one K (or V) tile
@@ -85,28 +94,41 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.v + base_kv), 0, kv_head_bytes, 0x00020000);
 
   // ---- Q fragment (B operand of K.Q^T): lane (r, h) holds Q[qrow][32h .. 32h+31] (any k order works as long as K uses the same)
-  i32x8 qf;
-  {
-    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + 32 * h, 0, 0);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + 32 * h + 16, 0, 0);
-    qf = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  // (head_dim 128: k-step ks covers columns 64ks .. 64ks+63)
+  i32x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + 64 * ks + 32 * h, 0, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)qrow * RB + 64 * ks + 32 * h + 16, 0, 0);
+    qf[ks] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
   }
 
   // ---- per-lane LDS addresses (absolute, opaque to hipcc)
   // K: row (32kb + r), bytes 32h .. 32h+31 = 16-byte chunks 2h, 2h+1, swizzled by (r >> 2) & 3 (conflict-free ds_read_b128)
-  const int kx = (r >> 2) & 3;
-  const lds_char *kptr0 = Kbuf + r * RB + (((2 * h) ^ kx) << 4), *kptr1 = Kbuf + r * RB + (((2 * h + 1) ^ kx) << 4);
-  asm volatile("" : "+v"(kptr0), "+v"(kptr1));
+  // (head_dim 128: rows of 128 bytes = 8 chunks, two rows per 64-bank line: chunks 4ks + 2h, 4ks + 2h + 1 swizzled by (r >> 1) & 7)
+  auto k_swz = [](int row) { return D == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
+  const int kx = k_swz(r);
+  const lds_char *kptr0[KS], *kptr1[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kptr0[ks] = Kbuf + r * RB + (((4 * ks + 2 * h) ^ kx) << 4);
+    kptr1[ks] = Kbuf + r * RB + (((4 * ks + 2 * h + 1) ^ kx) << 4);
+    asm volatile("" : "+v"(kptr0[ks]), "+v"(kptr1[ks]));
+  }
   // V: ds_read_b64_tr_b8. 16-lane group (h, c16 = (lane >> 4) & 1) covers d columns 32db + 16c16 ..+15; its lane 2q + pp supplies the
   // address of row q of the group's 8 rows, bytes 8pp .. 8pp+7: rows q = 0..3 -> keys 8g + 4h + q, q = 4..7 -> keys 8(g+1) + 4h + (q-4)
   // (g = 0, 2 per read; + 32kb), so the two result dwords are elements j = 16kb + 4g + 0..3 and 16kb + 4(g+1) + 0..3 of the operand.
   // Image: 16-byte chunk index ^ (((row >> 3) & 1) << 1): the two 4-row halves of a read sit in different 32-byte halves of the bank row.
+  // (head_dim 128: 128-byte rows, two per 64-bank line: the eight rows of a read -- keys 4h + 0..3 and 8 + 4h + 0..3 -- must spread
+  // over four chunk PAIRS per row parity: chunk index ^ ((bit 1 of the row | bit 3 of the row << 1) << 1); the group's two chunks of
+  // a 32-byte pair stay adjacent)
+  auto v_swz = [](int row) { return D == 64 ? (((row >> 3) & 1) << 1) : ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1); };
   const int vi = lane & 15, vq = vi >> 1, vpp = vi & 1, c16 = (lane >> 4) & 1;
   const int vrow = 8 * (vq >> 2) + 4 * h + (vq & 3);
   const lds_char *vptr[DB];
 #pragma unroll
   for (int db = 0; db < DB; ++db) {
-    vptr[db] = Vbuf + vrow * RB + (((2 * db + c16) ^ (((vq >> 2) & 1) << 1)) << 4) + 8 * vpp;
+    vptr[db] = Vbuf + vrow * RB + (((2 * db + c16) ^ v_swz(vrow)) << 4) + 8 * vpp;
     asm volatile("" : "+v"(vptr[db]));
   }
 
@@ -114,19 +136,24 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
   const int nT = (kv_end + BN - 1) / BN;
 
   // ---- LDS-DMA staging: one 1-KiB piece (16 rows) of K and one of V per wave and tile; the swizzles sit on the SOURCE address
-  static_assert(BN * RB == RW * 1024, "one piece per wave, tile and operand");
+  // (head_dim 128: two pieces of 8 rows per wave, tile and operand -- pieces w and w + 4, 32 rows apart: the swizzles repeat every 16)
+  constexpr int RPP = 1024 / RB, NPW = (BN / RPP) / RW;  // rows per piece; pieces per wave, tile and operand
+  static_assert((RW * RPP) % 16 == 0, "the piece stride must keep the swizzles");
   unsigned dma_ko, dma_vo;
   {
-    const int row = wave * 16 + lane / 4, pc = lane % 4;
-    dma_ko = (unsigned)(row * RB + ((pc ^ ((row >> 2) & 3)) << 4));
-    dma_vo = (unsigned)(row * RB + ((pc ^ (((row >> 3) & 1) << 1)) << 4));
+    const int row = wave * RPP + lane / CPR, pc = lane % CPR;
+    dma_ko = (unsigned)(row * RB + ((pc ^ k_swz(row)) << 4));
+    dma_vo = (unsigned)(row * RB + ((pc ^ v_swz(row)) << 4));
   }
   auto stage_dma = [&](int t, int buf) {  // tile t -> buffer buf (hipcc does not count these loads: the caller waits vmcnt(0))
-    const unsigned soff = (unsigned)t * TILE;
-    const unsigned lk = (unsigned)(__UINTPTR_TYPE__)Kbuf + buf * TILE + wave * 1024;
-    const unsigned lv = (unsigned)(__UINTPTR_TYPE__)Vbuf + buf * TILE + wave * 1024;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dma_ko), "s"(rk), "s"(soff) : "memory");
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lv), "v"(dma_vo), "s"(rv), "s"(soff) : "memory");
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+      const unsigned soff = (unsigned)t * TILE + j * (RW * 1024);
+      const unsigned lk = (unsigned)(__UINTPTR_TYPE__)Kbuf + buf * TILE + (wave + RW * j) * 1024;
+      const unsigned lv = (unsigned)(__UINTPTR_TYPE__)Vbuf + buf * TILE + (wave + RW * j) * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dma_ko), "s"(rk), "s"(soff) : "memory");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lv), "v"(dma_vo), "s"(rv), "s"(soff) : "memory");
+    }
   };
 
   f32x16 oacc[DB];
@@ -145,23 +172,28 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
 
   stage_dma(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  asm volatile("" : "+v"(qf));  // retire the Q loads here (hipcc otherwise drains vmcnt in front of every tile)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));  // retire the Q loads here (hipcc otherwise drains vmcnt in front of every tile)
   __syncthreads();
 
   // raw scores of the tile: s[kb][i] = S[q = r][key = kv0 + 32kb + (i & 3) + 8(i >> 2) + 4h], masked where the key is not visible
   auto scores = [&](auto bufc, f32x16 (&s)[2], const int kv0) __attribute__((always_inline)) {
     constexpr int buf = decltype(bufc)::value;
-    i32x8 kf[2];
+    i32x8 kf[2][KS];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      const u32x4 a = lds_read_b128(kptr0 + buf * TILE + kb * 32 * RB), b = lds_read_b128(kptr1 + buf * TILE + kb * 32 * RB);
-      kf[kb] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
-    }
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 a = lds_read_b128(kptr0[ks] + buf * TILE + kb * 32 * RB), b = lds_read_b128(kptr1[ks] + buf * TILE + kb * 32 * RB);
+        kf[kb][ks] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+      }
     f32x16 zero;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) s[kb] = mfma_f8(kf[kb], qf, zero);
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[kb] = mfma_f8(kf[kb][ks], qf[ks], ks == 0 ? zero : s[kb]);
     if ((CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk)) {  // tiles that cross the diagonal or the end of the sequence
       int h4 = 4 * h;
       asm volatile("" : "+v"(h4));  // pins the limit and the compares inside this branch
@@ -317,11 +349,11 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
 }
 
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, FA8_OCC) void fwd_fp8_kernel(Params p) {
+__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA8_OCC : FA8_OCC128)) void fwd_fp8_kernel(Params p) {
   fwd_fp8_body<D, CAUSAL>(p);
 }
 
-bool fp8pv_supported(int dtype, int D) { return dtype == FA_DTYPE_FP8_E4M3 && D == 64; }
+bool fp8pv_supported(int dtype, int D) { return dtype == FA_DTYPE_FP8_E4M3 && (D == 64 || D == 128); }
 
 template <int D, bool CAUSAL>
 static hipError_t launch8_one(const Params &p, hipStream_t s) {
@@ -337,7 +369,8 @@ static hipError_t launch8_one(const Params &p, hipStream_t s) {
 }
 
 hipError_t launch_fp8pv(const Params &p, int dtype, hipStream_t s) {
-  if (p.D != 64 || dtype != FA_DTYPE_FP8_E4M3) return hipErrorInvalidValue;
+  if (!fp8pv_supported(dtype, p.D)) return hipErrorInvalidValue;
+  if (p.D == 128) return p.is_causal ? launch8_one<128, true>(p, s) : launch8_one<128, false>(p, s);
   return p.is_causal ? launch8_one<64, true>(p, s) : launch8_one<64, false>(p, s);
 }
 

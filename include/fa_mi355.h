@@ -71,7 +71,7 @@ enum fa_variant {
   FA_VARIANT_MFMA16 = 10, /* FA_VARIANT_MFMA's workgroup (128 query rows, pre-scaled query operand) with every product on
                             v_mfma_f32_16x16x32 instead of 32x32x16: the chip holds a higher clock on that shape under
                             power-limited loops (f16 / bf16, head_dim 64) */
-  FA_VARIANT_MFMA_FP8PV = 11 /* fp8 inputs, head_dim 64: BOTH products on the scaled fp8 MFMA -- the probabilities are rounded to e4m3
+  FA_VARIANT_MFMA_FP8PV = 11 /* fp8 inputs, head_dim 64 or 128: BOTH products on the scaled fp8 MFMA -- the probabilities are rounded to e4m3
                             for the PV product (FA_VARIANT_MFMA / _EXACT keep them in bf16); see "fp8 probabilities" below */
 };
 
@@ -95,7 +95,7 @@ enum fa_status {
  *  lse           device pointer to B*H*N floats, contiguous [B,H,N]; may be NULL
  *  N             sequence length (queries == keys); any N >= 1
  *  D             head dim: 32, 64, 96, 128 or 256 for FA_VARIANT_MFMA (fp8 inputs: 64, 128, 256), 64 or 128 for
- *                FA_VARIANT_MFMA16 / _SPLIT2, 64 for _H64S2 / _SPLITKV / _FP8PV, <= 128 (multiple of 4) for the scalar variants
+ *                FA_VARIANT_MFMA16 / _SPLIT2 / _FP8PV, 64 for _H64S2 / _SPLITKV, <= 128 (multiple of 4) for the scalar variants
  *  scale         softmax scale (> 0); the reference passes 1/sqrt(D) (main.mm:13)
  *  dtype/variant enums above
  *  hip_stream    hipStream_t on the current device, or NULL
@@ -119,7 +119,7 @@ enum fa_status {
  * (measured: 4e-4 at N = 128, below 1e-4 from N = 1024 on, bf16). Every other kernel / dtype (FA_VARIANT_MFMA_EXACT, the split-KV
  * and paired-block kernels, fp8 inputs): |lse - exact| <= 1e-4 for |lse| <= ~10.
  *
- * fp8 probabilities. FA_VARIANT_MFMA_FP8PV (e4m3 inputs, D = 64; FA_VARIANT_AUTO's choice for grids that fill the chip) runs BOTH
+ * fp8 probabilities. FA_VARIANT_MFMA_FP8PV (e4m3 inputs, D = 64 or 128; FA_VARIANT_AUTO's choice for grids that fill the chip) runs BOTH
  * products on the fp8 matrix pipe: the probabilities are rounded to e4m3 (3 mantissa bits) on their way into the PV product, as the
  * inputs themselves were. Every softmax weight moves by a factor within 1 +- 2^-4, so
  *     |O - exact| <= 2^-4 * max_j |v_j|     (plus the bf16 rounding of O),

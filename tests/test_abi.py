@@ -56,7 +56,7 @@ def test_support_table(fa):
         assert fa.supported("bf16", "mfma", d) and fa.supported("f16", "mfma", d) and not fa.supported("bf16", "mfma16", d)
     assert fa.supported("fp8_e4m3", "mfma", 256) and not fa.supported("fp8_e4m3", "mfma", 32) and not fa.supported("fp8_e4m3", "mfma", 96)
     assert not fa.supported("bf16", "mfma", 48) and not fa.supported("bf16", "mfma", 512)
-    assert fa.supported("fp8_e4m3", "mfma_fp8pv", 64) and not fa.supported("fp8_e4m3", "mfma_fp8pv", 128) and not fa.supported("bf16", "mfma_fp8pv", 64)
+    assert fa.supported("fp8_e4m3", "mfma_fp8pv", 64) and fa.supported("fp8_e4m3", "mfma_fp8pv", 128) and not fa.supported("fp8_e4m3", "mfma_fp8pv", 256) and not fa.supported("bf16", "mfma_fp8pv", 64)
     assert fa.supported("bf16", "mfma_splitkv", 64) and not fa.supported("bf16", "mfma_splitkv", 128)  # head_dim 64 only since version 400
     lib = fa.load_library()
     assert lib.fa_resolve_variant(fa.DTYPES["bf16"], 64) == fa.VARIANTS["mfma"]

@@ -47,7 +47,7 @@ def test_driver_baseline_configs(tmp_path):
     got = {l.split(",")[0]: l.split(",") for l in r.stdout.splitlines() if l[:2] in ("c2", "c3", "c4", "c5")}
     # config 2 also through the kernel BASELINE.json names for it ("V2-style tiled kernel") and through the 128-row
     # matrix-core kernel, next to "auto"
-    assert set(got) == {"c2", "c2_v2", "c2_mfma", "c3", "c3_mfma32", "c4", "c5", "c5_bf16p"}
+    assert set(got) == {"c2", "c2_v2", "c2_mfma", "c3", "c3_mfma32", "c4", "c5", "c5_bf16p", "c5_d128", "c5_d128_bf16p"}
     assert float(got["c2_v2"][8]) > float(got["c2"][8]) > 0  # median ms: the scalar V2 kernel is the slow one
     assert got["c3"][6] == "bf16" and got["c3"][7] == "1" and float(got["c3"][9]) > 100  # TFLOP/s
     assert got["c5"][6] == "fp8_e4m3"

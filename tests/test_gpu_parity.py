@@ -609,7 +609,8 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
         (1, 8, 1024, 64, "fp8", True, "mfma_splitkv"),
         (1, 40, 1024, 64, "fp8", True, "mfma_split2"),     # fp8, causal, 320 blocks, N >= 1024: the eight-wave form
         (1, 80, 1024, 64, "fp8", True, "mfma_fp8pv"),      # 640 blocks: past the eight-wave form, the all-fp8 kernel
-        (1, 80, 1024, 128, "fp8", True, "mfma"),           # ... which exists for head_dim 64 only
+        (1, 80, 1024, 128, "fp8", True, "mfma_fp8pv"),     # ... at head_dim 128 too
+        (1, 8, 512, 256, "fp8", True, "mfma"),             # head_dim 256: the 128-row kernel with bf16 probabilities
     ]
     for (B, H, N, D, dtype, causal, want) in cases:
         fdt = fa.DTYPES[{"fp8": "fp8_e4m3"}.get(dtype, dtype)]
