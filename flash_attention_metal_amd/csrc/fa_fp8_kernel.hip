@@ -191,9 +191,9 @@ __device__ __forceinline__ void fwd_fp8_body(const Params &p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int ks = 0; ks < KS; ++ks)  // (k-step outermost: the two tuples' chains alternate, no MFMA waits for its predecessor)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s[kb] = mfma_f8(kf[kb][ks], qf[ks], ks == 0 ? zero : s[kb]);
+      for (int kb = 0; kb < 2; ++kb) s[kb] = mfma_f8(kf[kb][ks], qf[ks], ks == 0 ? zero : s[kb]);
     if ((CAUSAL && (kv0 + BN - 1 > qw0 + coff)) || (kv0 + BN > p.Nk)) {  // tiles that cross the diagonal or the end of the sequence
       int h4 = 4 * h;
       asm volatile("" : "+v"(h4));  // pins the limit and the compares inside this branch

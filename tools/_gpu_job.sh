@@ -1,8 +1,9 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "fp8 or auto_routes" > gpurun_out/fp8_tests.log 2>&1 || { tail -40 gpurun_out/fp8_tests.log; exit 1; }
-tail -3 gpurun_out/fp8_tests.log
 L=flash_attention_metal_amd/csrc/libfa_mi355.so
-timeout -k 10 400 python tools/ab.py $L:4 $L:11 --shapes c5d128,c5d128bf --rounds 5 --iters 10 > gpurun_out/ab_fp8_d128.log 2>&1 || true
-cat gpurun_out/ab_fp8_d128.log
+timeout -k 10 400 python tools/ab.py tools/ab/lib_fp8d128_v0.so:11 $L:11 --shapes c5d128,c5 --rounds 5 --iters 10 > gpurun_out/ab_fp8_d128b.log 2>&1
+cat gpurun_out/ab_fp8_d128b.log
+timeout -k 10 300 python3 tools/pmc.py gpurun_out/pmc_c5d128 2 16 8192 128 fp8 1 0 $L --script run_lib.py --iters 6 --sets sq1,sq2 > gpurun_out/pmc_c5d128.log 2>&1
+python3 -c "
+import json; r=json.load(open('gpurun_out/pmc_c5d128/pmc_summary.json')); print(r['derived'])"
