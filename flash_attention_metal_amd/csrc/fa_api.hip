@@ -134,7 +134,9 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
     case FA_VARIANT_MFMA_SPLITKV: snprintf(name, sizeof(name), "fa::fwd_splitkv_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_SPLIT2: snprintf(name, sizeof(name), "fa::fwd_mfma_split2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_H64S2: snprintf(name, sizeof(name), "fa::fwd_mfma_h64s2_kernel<%s, %d, %s>", tag, D, c); break;
-    case FA_VARIANT_MFMA16: snprintf(name, sizeof(name), "fa::fwd_mfma16_kernel<%s, %d, %s>", tag, D, c); break;
+    case FA_VARIANT_MFMA16:
+      snprintf(name, sizeof(name), "fa::fwd_mfma16_kernel<%s, %d, %s, %d>", tag, D, c, fa::mfma16_waves(D, B * H, N, N, is_causal));
+      break;
     case FA_VARIANT_MFMA_FP8PV: snprintf(name, sizeof(name), "fa::fwd_fp8_kernel<%d, %s>", D, c); break;
     case FA_VARIANT_MFMA:
       snprintf(name, sizeof(name), "fa::fwd_mfma_kernel<%s, %d, %s, %s>", tag, D, c,

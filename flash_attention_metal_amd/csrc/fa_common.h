@@ -76,6 +76,7 @@ hipError_t launch_mfma_h64s2(const Params &p, int dtype, hipStream_t s);
 bool mfma_h64s2_supported(int dtype, int D);
 hipError_t launch_mfma16(const Params &p, int dtype, hipStream_t s);
 bool mfma16_supported(int dtype, int D);
+int mfma16_waves(int D, int BH, int N, int Nk, int is_causal);  // 4 or 8 waves (128 / 256 query rows) per workgroup
 hipError_t launch_fp8pv(const Params &p, int dtype, hipStream_t s);
 bool fp8pv_supported(int dtype, int D);
 hipError_t launch_splitkv(const Params &p, int dtype, hipStream_t s);

@@ -78,12 +78,12 @@ template <> struct MT16<F16> {
 // value of lane ^ 16 / lane ^ 32 (rare path and epilogue only: ds_bpermute, no LDS memory)
 __device__ __forceinline__ float xlane(float x, int mask) { return __shfl_xor(x, mask, 64); }
 
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, int RW>
 __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   using M = MT16<Tag>;
   using vec8 = typename M::vec8;
   using elem = typename M::elem;
-  constexpr int RW = BM / WM;      // waves
+  constexpr int BMR = RW * WM;     // query rows of the block (RW waves of 32)
   constexpr int RB = D * 2;        // row bytes (global and LDS)
   constexpr int CPR = D / 8;       // 16-byte chunks per row
   constexpr int KS = D / 32;       // 32-wide k-steps of the score product
@@ -109,7 +109,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   long long base, base_kv;
   head_bases(bh, p, base, base_kv);
   const int coff = p.Nk - p.N;  // causal, Nq != Nk: bottom-right aligned (key j visible to query i iff j <= i + coff)
-  const int q0 = qb * BM;
+  const int q0 = qb * BMR;
   const int qw0 = q0 + wave * WM;
 
   const unsigned head_bytes = (unsigned)p.N * RB, kv_head_bytes = (unsigned)p.Nk * RB;
@@ -147,7 +147,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
     asm volatile("" : "+v"(vptr[dt]));
   }
 
-  const int kv_end = CAUSAL ? min(p.Nk, q0 + BM + coff) : p.Nk;
+  const int kv_end = CAUSAL ? min(p.Nk, q0 + BMR + coff) : p.Nk;
   const int nT = (kv_end + BNK - 1) / BNK;
 
   // ---- LDS-DMA staging: wave w moves the 1-KiB pieces w, w + 4, ... of each tile; inside a piece the LDS image is
@@ -501,18 +501,18 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   }
 }
 
-template <typename Tag, int D, bool CAUSAL>
-__global__ __launch_bounds__(NTHREADS, (D == 64 ? FA16_OCC : FA16_OCC128)) void fwd_mfma16_kernel(Params p) {
-  fwd_mfma16_body<Tag, D, CAUSAL>(p);
+template <typename Tag, int D, bool CAUSAL, int RW>
+__global__ __launch_bounds__(64 * RW, (D == 64 ? FA16_OCC : FA16_OCC128)) void fwd_mfma16_kernel(Params p) {
+  fwd_mfma16_body<Tag, D, CAUSAL, RW>(p);
 }
 
 bool mfma16_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128); }
 
-template <typename Tag, int D, bool CAUSAL>
+template <typename Tag, int D, bool CAUSAL, int RW>
 static hipError_t launch16_one(const Params &p, hipStream_t s) {
-  const int nQ = (p.N + BM - 1) / BM;
+  const int nQ = (p.N + RW * WM - 1) / (RW * WM);
   const size_t smem = 4 * (size_t)(D == 128 ? FA16_BN128 : BN) * D * 2;
-  auto kern = fwd_mfma16_kernel<Tag, D, CAUSAL>;
+  auto kern = fwd_mfma16_kernel<Tag, D, CAUSAL, RW>;
   if (smem > 48 * 1024) {
     hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
     if (e != hipSuccess) return e;
@@ -521,15 +521,43 @@ static hipError_t launch16_one(const Params &p, hipStream_t s) {
   pp.head_group = causal_head_group(p, D, 2);
   set_block_divisors(pp, nQ, pp.head_group);
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
-  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(NTHREADS), smem, s, pp);
+  hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(64 * RW), smem, s, pp);
   return hipGetLastError();
 }
 
+// Waves per workgroup: 4 (128 query rows) or 8 (256 rows, the same 32 rows per wave: eight waves share every K / V tile, so the
+// L2 -> LDS stream and its issue slots halve, and a workgroup that is alone on its CU in the launch's tail still runs two waves per SIMD).
+// The price is the causal diagonal (a block's lower waves idle through up to seven more tiles' barriers), twice the weight of the
+// heaviest block, and a wider spread of launch times on large causal grids. Measured interleaved on warm clocks, medians, bf16 unless
+// noted (profiles/r04/ab_mfma16_eight_waves_steady_state.log):
+//   non-causal  N = 2048 / 4096 (64 heads) +5.1 / +4.6 %, N = 8192 +4.1 %, 32 heads x 2048 +1.2 % (256 workgroups: level)
+//   causal      64 heads x 4096 (config 3) +3.0 %, f16 +3.7 %, x 5120 +1.5 %; but 80 .. 256 heads x 4096 -2.3 .. -6.3 % (best times level),
+//               48 heads level, 64 heads x 2048 -4.8 %, x 6144 -0.9 %, x 8192 +0.7 %, x 16384 +0.4 %, 48 heads x 8192 -0.2 %
+//   head_dim 128: non-causal 32 heads x 8192 +2.5 %, causal level
+// -> eight waves for non-causal grids of at least 512 such workgroups, and under the mask only for the two-round grids of config 3's
+// kind (1024 .. 1279 workgroups of 256 rows at 4096 <= N < 6144), where the launch is tail-dominated.
+int mfma16_waves(int D, int BH, int N, int Nk, int is_causal) {
+#ifdef FA16_FORCE_RW
+  return FA16_FORCE_RW;
+#endif
+  const long long b256 = (long long)BH * ((N + 255) / 256);
+  if (D == 128) return (!is_causal && Nk >= 8192 && b256 >= 1024) ? 8 : 4;
+  if (!is_causal) return (Nk >= 1024 && b256 >= 512) ? 8 : 4;
+  return (Nk >= 4096 && Nk < 6144 && b256 >= 1024 && b256 < 1280) ? 8 : 4;
+}
+
 hipError_t launch_mfma16(const Params &p, int dtype, hipStream_t s) {
+  const bool w8 = mfma16_waves(p.D, p.B * p.H, p.N, p.Nk, p.is_causal) == 8 && (p.D == 64 || !p.is_causal);
   auto go = [&](auto tag) -> hipError_t {
     using Tag = decltype(tag);
-    if (p.D == 64) return p.is_causal ? launch16_one<Tag, 64, true>(p, s) : launch16_one<Tag, 64, false>(p, s);
-    if (p.D == 128) return p.is_causal ? launch16_one<Tag, 128, true>(p, s) : launch16_one<Tag, 128, false>(p, s);
+    if (p.D == 64) {
+      if (w8) return p.is_causal ? launch16_one<Tag, 64, true, 8>(p, s) : launch16_one<Tag, 64, false, 8>(p, s);
+      return p.is_causal ? launch16_one<Tag, 64, true, 4>(p, s) : launch16_one<Tag, 64, false, 4>(p, s);
+    }
+    if (p.D == 128) {
+      if (w8) return launch16_one<Tag, 128, false, 8>(p, s);  // (non-causal only: mfma16_waves)
+      return p.is_causal ? launch16_one<Tag, 128, true, 4>(p, s) : launch16_one<Tag, 128, false, 4>(p, s);
+    }
     return hipErrorInvalidValue;
   };
   return dtype == FA_DTYPE_F16 ? go(F16{}) : go(BF16{});

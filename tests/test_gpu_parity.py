@@ -676,6 +676,27 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, varia
     torch.cuda.synchronize()
 
 
+def test_mfma16_eight_wave_workgroups(fa, oracle_mod):
+    """The 16x16x32 kernel runs 256-row workgroups (eight waves sharing every K / V tile) where its launch rule says so
+    (csrc/fa_mfma16_kernel.hip, mfma16_waves): non-causal grids of at least 512 such workgroups, the two-round causal grids of config 3's
+    kind, long non-causal head_dim-128 grids. Ragged lengths on both sides of the 256-row blocks, both dtypes, rows sampled across block
+    and wave boundaries. (The whole mfma16 parity suite was also run once with eight waves forced on EVERY shape: FA16_FORCE_RW=8 build,
+    28 tests, profiles/r04/tests_mfma16_eight_waves_forced.log.)"""
+    lib = fa.load_library()
+    # which instantiation AUTO launches (the kernel name carries the waves per workgroup)
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4096, 1).decode().endswith("64, true, 8>")    # config 3
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4100, 1).decode().endswith("64, true, 8>")
+    assert lib.fa_fwd_kernel_name(2, 64, 8, 16, 4096, 1).decode().endswith("64, true, 4>")    # twice the heads: four waves
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 1).decode().endswith("64, true, 4>")
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 0).decode().endswith("64, false, 8>")
+    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 8192, 0).decode().endswith("128, false, 8>")
+    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 16384, 1).decode().endswith("128, true, 4>")  # config 4's shard
+    _full_size(fa, oracle_mod, 1, 128, 1000, 64, "bf16", False, heads=[(0, 0), (0, 127)], variant="mfma16")   # 512 workgroups of 256 rows, ragged
+    _full_size(fa, oracle_mod, 4, 16, 4100, 64, "f16", True, heads=[(0, 0), (3, 15)], variant="mfma16")       # 1088 workgroups, causal, ragged
+    _full_size(fa, oracle_mod, 4, 16, 2304, 64, "bf16", False, heads=[(1, 7)], variant="auto")                # AUTO's non-causal route
+    _full_size(fa, oracle_mod, 1, 32, 8192, 128, "bf16", False, heads=[(0, 5)], nrows=24, variant="mfma16")   # head_dim 128
+
+
 @pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2", "mfma16"])
 def test_config2_full(fa, oracle_mod, variant):  # seqlen=1024, D=64, B=1, H=8, fp16, non-causal
     # BASELINE configs[1] names the "V2-style tiled kernel": variant tiled_v2 (kernels.metal:462-596) runs it at
