@@ -106,19 +106,30 @@ int fa_resolve_variant_for(int dtype, int D, int B, int H, int N, int is_causal)
   if (fa::mfma_h64s2_supported(dtype, D) && N >= 256 && blocks64 <= 512) return FA_VARIANT_MFMA_H64S2;
   // up to one 128-row workgroup per CU: the block's tiles are the critical path -- eight waves, even / odd tiles
   // (h=32, N=1024 causal: 16.1 -> 14.2 us; h=8, N=2048: 27.3 -> 22.0 us, split-KV 25.1)
-  if (fa::mfma_split2_supported(dtype, D) && N >= 512 && blocks128 <= 256) return FA_VARIANT_MFMA_SPLIT2;
+  // (e4m3 inputs at head_dim 128: the all-fp8 kernel is ahead of the eight-wave form except on small grids of long sequences --
+  // 32 heads x 512 / 2048: 11.4 -> 10.3 / 36.8 -> 32.7 us, 8 heads x 4096: 50.6 vs 53.6; profiles/r04/auto_check_late.log)
+  const bool fp8_d128 = dtype == FA_DTYPE_FP8_E4M3 && D == 128;
+  if (fa::mfma_split2_supported(dtype, D) && N >= 512 && blocks128 <= 256 && !(fp8_d128 && N < 4096)) return FA_VARIANT_MFMA_SPLIT2;
   // causal, two workgroups' worth of blocks per CU of which half are light: the heaviest block's 32+ tiles are still the critical
   // path (32 heads x 2048: 28.9 -> 25.9 us at head_dim 64, 45.8 -> 42.5 at 128, fp8 29.3 -> 24.6; at N = 1024 the plain kernel
   // wins again; profiles/r03/auto_check.log)
   // (fp8 inputs at head_dim 64 already from N = 1024: 64 heads x 1024, 16.7 -> 14.7 us)
   const int n_min = (dtype == FA_DTYPE_FP8_E4M3 && D == 64) ? 1024 : 2048;
-  if (fa::mfma_split2_supported(dtype, D) && is_causal && N >= n_min && blocks128 <= 512) return FA_VARIANT_MFMA_SPLIT2;
+  if (fa::mfma_split2_supported(dtype, D) && is_causal && N >= n_min && blocks128 <= 512 && !fp8_d128) return FA_VARIANT_MFMA_SPLIT2;
   // head_dim 64, 16-bit inputs, grids that fill the chip: the same workgroup on the 16x16x32 instruction with its row sums on the matrix
   // core -- config 3 +2 %, N >= 4096 non-causal / N >= 8192 causal +4.5..5.7 %; level at N = 2048, 1-2 % behind at N = 1024 (its
   // first tile pays a second score pass) (profiles/r04/ab_mfma16_ones_vs_adds.log)
   // head_dim 128: from N = 8192 on (config 4 shard 1259-1300 -> 1323-1331 TFLOP/s, non-causal N = 8192 +4..5.7 %; level at N <= 4096;
   // profiles/r04/ab_mfma16_d128*.log)
-  if (fa::mfma16_supported(dtype, D) && N >= (D == 64 ? 2048 : 8192)) return FA_VARIANT_MFMA16;
+  // (late round 4, on warm clocks, profiles/r04/ab_auto_short_sequences_mfma16.log: with its first tile free of the second score pass it is
+  // also ahead from N = 1536 on under the mask (+4 %; level at 1024) and, without the mask, from N = 512 on for grids of at least 512
+  // workgroups (+2..6 %, eight waves per workgroup there: mfma16_waves))
+  if (fa::mfma16_supported(dtype, D)) {
+    // (head_dim 128: since the first tile lost its second score pass it is ahead from N = 2048 on, +5.5..7 % at 4 x 16 heads x 2048 / 4096
+    // causal and non-causal; without the mask from 1024 on, +4..5 %; auto_check_late.log)
+    const bool take = D == 64 ? (is_causal ? N >= 1536 : (N >= 2048 || (N >= 512 && blocks128 >= 512))) : (is_causal ? N >= 2048 : N >= 1024);
+    if (take) return FA_VARIANT_MFMA16;
+  }
   // fp8 inputs, head_dim 64, grids that fill the chip: both products on the fp8 matrix pipe (config 5: 1215-1245 -> 1364-1461 TFLOP/s,
   // profiles/r04/ab_fp8pv_*.log). Its probabilities are e4m3 (include/fa_mi355.h, "fp8 probabilities"); FA_VARIANT_MFMA keeps them bf16
   if (fa::fp8pv_supported(dtype, D)) return FA_VARIANT_MFMA_FP8PV;

@@ -534,7 +534,7 @@ static hipError_t launch16_one(const Params &p, hipStream_t s) {
 //   causal      64 heads x 4096 (config 3) +3.0 %, f16 +3.7 %, x 5120 +1.5 %; but 80 .. 256 heads x 4096 -2.3 .. -6.3 % (best times level),
 //               48 heads level, 64 heads x 2048 -4.8 %, x 6144 -0.9 %, x 8192 +0.7 %, x 16384 +0.4 %, 48 heads x 8192 -0.2 %
 //   head_dim 128: non-causal 32 heads x 8192 +2.5 %, causal level
-// -> eight waves for non-causal grids of at least 512 such workgroups, and under the mask only for the two-round grids of config 3's
+// (N = 512, 256 / 512 heads: +3.4 % over four waves) -> eight waves for non-causal grids of at least 512 such workgroups, and under the mask only for the two-round grids of config 3's
 // kind (1024 .. 1279 workgroups of 256 rows at 4096 <= N < 6144), where the launch is tail-dominated.
 int mfma16_waves(int D, int BH, int N, int Nk, int is_causal) {
 #ifdef FA16_FORCE_RW
@@ -542,7 +542,7 @@ int mfma16_waves(int D, int BH, int N, int Nk, int is_causal) {
 #endif
   const long long b256 = (long long)BH * ((N + 255) / 256);
   if (D == 128) return (!is_causal && Nk >= 8192 && b256 >= 1024) ? 8 : 4;
-  if (!is_causal) return (Nk >= 1024 && b256 >= 512) ? 8 : 4;
+  if (!is_causal) return (Nk >= 512 && b256 >= 512) ? 8 : 4;
   return (Nk >= 4096 && Nk < 6144 && b256 >= 1024 && b256 < 1280) ? 8 : 4;
 }
 

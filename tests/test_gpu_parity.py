@@ -600,11 +600,19 @@ def test_auto_routes_reach_every_kernel_and_match_the_oracle(fa, oracle_mod):
         (1, 32, 2048, 64, "bf16", True, "mfma_split2"),    # causal, 512 blocks, N >= 2048: still the eight-wave form
         (1, 32, 2048, 64, "bf16", False, "mfma16"),        # ... not without the mask: head_dim 64, 16-bit inputs, N >= 2048 -> the 16x16x32 kernel
         (1, 80, 2048, 64, "f16", True, "mfma16"),          # causal, 1280 blocks of 128 rows (past the eight-wave form), N >= 2048
-        (1, 80, 2047, 64, "bf16", True, "mfma"),           # ... N < 2048: the 32x32x16 kernel
+        (1, 80, 1535, 64, "bf16", True, "mfma"),           # ... N < 1536: the 32x32x16 kernel
+        (1, 80, 1536, 64, "bf16", True, "mfma16"),
+        (1, 128, 1024, 64, "bf16", False, "mfma16"),       # without the mask from N = 512 on, for grids of at least 512 workgroups of 128 rows
+        (1, 256, 512, 64, "f16", False, "mfma16"),
+        (1, 255, 511, 64, "bf16", False, "mfma"),
         (1, 80, 2048, 64, "fp8", True, "mfma_fp8pv"),      # ... fp8 inputs have no 16x16x32 kernel: the all-fp8 kernel on grids that fill the chip
         (1, 64, 1024, 64, "bf16", True, "mfma"),           # ... and not at N = 1024
-        (1, 32, 4096, 128, "bf16", True, "mfma"),          # head_dim-128 sequences below 8192: the 32x32x16 128-row kernel
-        (1, 16, 8192, 128, "bf16", True, "mfma16"),        # ... from 8192 on (config 4's shape family): its 16x16x32 form
+        (1, 64, 1024, 128, "bf16", True, "mfma"),          # head_dim-128 causal sequences below 2048: the 32x32x16 128-row kernel
+        (1, 64, 2048, 128, "bf16", True, "mfma16"),        # ... from 2048 on (without the mask from 1024 on) its 16x16x32 form
+        (1, 64, 1024, 128, "f16", False, "mfma16"),
+        (1, 32, 2048, 128, "fp8", True, "mfma_fp8pv"),     # e4m3 at head_dim 128: the all-fp8 kernel also on grids the eight-wave form takes at 64
+        (1, 8, 4096, 128, "fp8", True, "mfma_split2"),     # ... except small grids of long sequences
+        (1, 16, 8192, 128, "bf16", True, "mfma16"),        # (config 4's shape family)
         (1, 4, 300, 96, "bf16", True, "mfma"),             # head dims only the 128-row kernel has
         (1, 8, 1024, 64, "fp8", True, "mfma_splitkv"),
         (1, 40, 1024, 64, "fp8", True, "mfma_split2"),     # fp8, causal, 320 blocks, N >= 1024: the eight-wave form

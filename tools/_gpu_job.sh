@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
-tail -3 gpurun_out/gpu_tests_full.log
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_rw8.json 2> gpurun_out/bench_rw8.err
-head -c 600 gpurun_out/bench_rw8.json; echo
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "auto_routes or eight_wave or config3 or config2" > gpurun_out/routes_tests.log 2>&1 || { tail -40 gpurun_out/routes_tests.log; exit 1; }
+tail -3 gpurun_out/routes_tests.log
+timeout -k 10 600 python tools/auto_check.py > gpurun_out/auto_check.log 2>&1 || true
+tail -30 gpurun_out/auto_check.log

@@ -14,6 +14,8 @@ SHAPES = {  # name: (B, H, N, D, dtype, causal)
     "nc2k": (4, 16, 2048, 64, "bf16", 0), "c3f16": (4, 16, 4096, 64, "f16", 1), "h32nc4k": (1, 32, 4096, 64, "bf16", 0), "c3k": (4, 16, 3072, 64, "bf16", 1),
     "b5n4k": (5, 16, 4096, 64, "bf16", 1), "b6n4k": (6, 16, 4096, 64, "bf16", 1), "b7n4k": (7, 16, 4096, 64, "bf16", 1), "c6k": (4, 16, 6144, 64, "bf16", 1), "c5k": (4, 16, 5120, 64, "bf16", 1),
     "b2nc2k": (2, 16, 2048, 64, "bf16", 0), "nc1k": (4, 16, 1024, 64, "bf16", 0), "b8nc1k": (8, 16, 1024, 64, "bf16", 0), "b8nc2k": (8, 16, 2048, 64, "bf16", 0), "b3n8k": (3, 16, 8192, 64, "bf16", 1),
+    "b16nc1k": (16, 16, 1024, 64, "bf16", 0), "b16nc512": (16, 16, 512, 64, "bf16", 0), "b32nc512": (32, 16, 512, 64, "bf16", 0), "b8nc1536": (8, 16, 1536, 64, "bf16", 0),
+    "b16c1k": (16, 16, 1024, 64, "bf16", 1), "b8c1k": (8, 16, 1024, 64, "bf16", 1), "b8c1536": (8, 16, 1536, 64, "bf16", 1), "b32c512": (32, 16, 512, 64, "bf16", 1), "b16c1kf16": (16, 16, 1024, 64, "f16", 1),
     "c3x4": (16, 16, 4096, 64, "bf16", 1), "c3x3": (12, 16, 4096, 64, "bf16", 1), "c3x2": (8, 16, 4096, 64, "bf16", 1), "c3h": (2, 16, 4096, 64, "bf16", 1), "c3h48": (3, 16, 4096, 64, "bf16", 1),
     "d128c1k": (2, 32, 1024, 128, "bf16", 1), "d128c2k": (2, 32, 2048, 128, "bf16", 1), "d128c4k": (1, 32, 4096, 128, "bf16", 1),
     "d128h8n1k": (1, 8, 1024, 128, "bf16", 0), "d128h8n1kc": (1, 8, 1024, 128, "bf16", 1), "d128h8n2kc": (1, 8, 2048, 128, "bf16", 1), "d128h16n512c": (1, 16, 512, 128, "bf16", 1), "d128h32n256": (1, 32, 256, 128, "bf16", 0), "d128h8n4kc": (1, 8, 4096, 128, "bf16", 1),
