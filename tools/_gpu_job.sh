@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "auto_routes or eight_wave or config3 or config2" > gpurun_out/routes_tests.log 2>&1 || { tail -40 gpurun_out/routes_tests.log; exit 1; }
-tail -3 gpurun_out/routes_tests.log
-timeout -k 10 600 python tools/auto_check.py > gpurun_out/auto_check.log 2>&1 || true
-tail -30 gpurun_out/auto_check.log
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
+tail -3 gpurun_out/gpu_tests_full.log
+timeout -k 10 1500 bash tools/collect_profiles.sh r04c > gpurun_out/collect_r04c.log 2>&1 || { tail -30 gpurun_out/collect_r04c.log; exit 1; }
+tail -32 gpurun_out/collect_r04c.log
