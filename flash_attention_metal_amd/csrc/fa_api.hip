@@ -79,6 +79,7 @@ int fa_supported(int dtype, int variant, int D) {
 }
 int fa_resolve_variant(int dtype, int D) {
   if (fa::mfma_supported(dtype, D)) return FA_VARIANT_MFMA;
+  if (fa::mfma16_supported(dtype, D)) return FA_VARIANT_MFMA16;  // 16-bit inputs, the other multiples of 8 up to 128: zero-padded rows
   if (fa::tiled_v2_supported(dtype, D)) return FA_VARIANT_TILED_V2;
   return FA_ERR_UNSUPPORTED;
 }
@@ -146,7 +147,8 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
     case FA_VARIANT_MFMA_SPLIT2: snprintf(name, sizeof(name), "fa::fwd_mfma_split2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_H64S2: snprintf(name, sizeof(name), "fa::fwd_mfma_h64s2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA16:
-      snprintf(name, sizeof(name), "fa::fwd_mfma16_kernel<%s, %d, %s, %d>", tag, D, c, fa::mfma16_waves(D, B * H, N, N, is_causal));
+      snprintf(name, sizeof(name), "fa::fwd_mfma16_kernel<%s, %d, %s, %d, %s>", tag, (D == 64 || D == 128) ? D : (D < 64 ? 64 : 128), c,
+               fa::mfma16_waves(D, B * H, N, N, is_causal), (D == 64 || D == 128) ? "false" : "true");
       break;
     case FA_VARIANT_MFMA_FP8PV: snprintf(name, sizeof(name), "fa::fwd_fp8_kernel<%d, %s>", D, c); break;
     case FA_VARIANT_MFMA:
@@ -189,6 +191,9 @@ int fa_fwd(const void *q, const void *k, const void *v, void *o, float *lse, int
   // by the buffer descriptor, but the offset itself must not wrap)
   if ((double)(N + 128) * D * fa_dtype_in_bytes(dtype) >= 4294967296.0)
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: one head exceeds 4 GiB");
+  // head dims without a kernel of their own run on zero-padded rows whose padding is fetched from offset 2^31 + ... (fa_mfma16_kernel.hip, PAD)
+  if (!fa::mfma_supported(dtype, D) && fa::mfma16_supported(dtype, D) && (double)(N + 128) * D * 2 >= 2147483648.0)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd: one head exceeds 2 GiB (head dims on padded rows)");
   if ((long long)B * H > 0x7fffffffLL / ((N + 127) / 128))
     return fail(FA_ERR_INVALID_ARG, "fa_fwd: grid too large");
   if (variant == FA_VARIANT_AUTO) {
@@ -249,9 +254,12 @@ int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
   if (is_causal && Nk < Nq)
     return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: causal needs Nk >= Nq (bottom-right alignment would leave empty rows)");
   if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: scale=%g must be > 0", (double)scale);
-  if (!fa::mfma_supported(dtype, D))
-    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: needs the matrix-core kernel (f16/bf16: D=32|64|96|128|256; fp8: D=64|128|256), got dtype=%s D=%d",
+  const bool padded_dim = !fa::mfma_supported(dtype, D) && fa::mfma16_supported(dtype, D);  // (zero-padded rows of the 16x16x32 kernel)
+  if (!fa::mfma_supported(dtype, D) && !padded_dim)
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_ex: needs a matrix-core kernel (f16/bf16: D a multiple of 8 up to 128, or 256; fp8: D=64|128|256), got dtype=%s D=%d",
                 fa_dtype_name(dtype), D);
+  if (padded_dim && (double)(std::max(Nq, Nk) + 128) * D * 2 >= 2147483648.0)
+    return fail(FA_ERR_INVALID_ARG, "fa_fwd_ex: one head exceeds 2 GiB (head dims on padded rows)");
   const int sm = dtype == FA_DTYPE_FP8_E4M3 ? 16 : 8;
   if (q_head_stride < (long long)Nq * D || kv_head_stride < (long long)Nk * D || (q_batch_stride % sm) || (q_head_stride % sm) ||
       (kv_batch_stride % sm) || (kv_head_stride % sm) || (Hq > 1 && B > 1 && q_batch_stride < q_head_stride) ||
@@ -279,6 +287,7 @@ int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
     const bool small_grid = D == 64 && fa::splitkv_supported(dtype, D) && Nk > 64 && blocks128 <= 64;
     // the 16x16x32 kernel where fa_fwd's AUTO takes it: head_dim 64, 16-bit inputs, long key sequences on a grid that fills the chip
     variant = small_grid ? FA_VARIANT_MFMA_SPLITKV
+              : padded_dim ? FA_VARIANT_MFMA16
               : (fa::mfma16_supported(dtype, D) && Nk >= (D == 64 ? 2048 : 8192) && blocks128 > 512) ? FA_VARIANT_MFMA16 : FA_VARIANT_MFMA;
   }
   // the kernels that take the generalised problem (key/value heads, Nk): the 128-row kernel with / without its pre-scaled operand, its

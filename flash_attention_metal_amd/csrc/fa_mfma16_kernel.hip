@@ -78,7 +78,12 @@ template <> struct MT16<F16> {
 // value of lane ^ 16 / lane ^ 32 (rare path and epilogue only: ds_bpermute, no LDS memory)
 __device__ __forceinline__ float xlane(float x, int mask) { return __shfl_xor(x, mask, 64); }
 
-template <typename Tag, int D, bool CAUSAL, int RW>
+// PAD: head dims other than 64 / 128 (any multiple of 8 below 128 that has no kernel of its own: 40, 48, 72, 80, 112, ...) run this
+// instantiation on ZERO-PADDED rows, as the backward does (fa_bwd_kernels.hip, FA_BWD_PAD): rows keep their packed pitch of p.D elements
+// in global memory, the LDS images and register fragments have the kernel's pitch, and every 16-byte chunk at or past column p.D is
+// fetched from an offset outside the buffer descriptor's range, which reads as zeros for register loads and LDS-DMA alike. The padding
+// adds 0 to every score and its O columns are never stored.
+template <typename Tag, int D, bool CAUSAL, int RW, bool PAD>
 __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   using M = MT16<Tag>;
   using vec8 = typename M::vec8;
@@ -112,7 +117,9 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   const int q0 = qb * BMR;
   const int qw0 = q0 + wave * WM;
 
-  const unsigned head_bytes = (unsigned)p.N * RB, kv_head_bytes = (unsigned)p.Nk * RB;
+  const int GRB = PAD ? p.D * 2 : RB;  // row bytes in global memory
+  auto gcol = [&](int chunk) -> unsigned { return (!PAD || chunk * 8 < p.D) ? (unsigned)chunk * 16 : 0x80000000u; };  // (heads below 2 GiB: fa_fwd)
+  const unsigned head_bytes = (unsigned)p.N * GRB, kv_head_bytes = (unsigned)p.Nk * GRB;
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.q + base * 2), 0, head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.k + base_kv * 2), 0, kv_head_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.v + base_kv * 2), 0, kv_head_bytes, 0x00020000);
@@ -123,7 +130,7 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)(qw0 + 16 * qt + c) * RB + 64 * ks + 16 * g, 0, 0);
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rq, (unsigned)(qw0 + 16 * qt + c) * GRB + gcol(4 * ks + g), 0, 0);
       qf[qt][ks] = __builtin_bit_cast(vec8, t);
     }
 
@@ -160,13 +167,13 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
     const int row = wave * RPP + lane / CPR, pc = lane % CPR;
     const int skx = (D == 64) ? ((row >> 1) & 7) : (row & 15);
     const int svx = (D == 64) ? (((row >> 1) & 3) << 1) : ((row & 7) << 1);
-    dma_kvo = (unsigned)(row * RB + ((pc ^ skx) << 4));
-    dma_vvo = (unsigned)(row * RB + ((pc ^ svx) << 4));
+    dma_kvo = (unsigned)(row * GRB) + gcol(pc ^ skx);
+    dma_vvo = (unsigned)(row * GRB) + gcol(pc ^ svx);
   }
   auto stage_dma = [&](int t, int buf) {  // tile t -> buffer buf (hipcc does not count these loads: the caller waits vmcnt(0))
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
-      const unsigned soff = (unsigned)t * TILE + j * (RW * 1024);
+      const unsigned soff = PAD ? (unsigned)(t * BNK + j * RW * RPP) * GRB : (unsigned)t * TILE + j * (RW * 1024);
       const unsigned lk = (unsigned)(__UINTPTR_TYPE__)Kbuf + buf * TILE + (wave + RW * j) * 1024;
       const unsigned lv = (unsigned)(__UINTPTR_TYPE__)Vbuf + buf * TILE + (wave + RW * j) * 1024;
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lk), "v"(dma_kvo), "s"(rk), "s"(soff) : "memory");
@@ -496,23 +503,23 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
       const int idx = it * 64 + lane;
       const int row = idx / CPR, ch = idx % CPR;
       const u32x4 vv = lds_read_b128(Ot + row * RB + ((ch ^ (row & (CPR - 1))) << 4));
-      if (qw0 + row < p.N) *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * D + ch * 8) = vv;
+      if (qw0 + row < p.N && (!PAD || ch * 8 < p.D)) *reinterpret_cast<u32x4 *>(Og + (long long)(qw0 + row) * (PAD ? p.D : D) + ch * 8) = vv;
     }
   }
 }
 
-template <typename Tag, int D, bool CAUSAL, int RW>
+template <typename Tag, int D, bool CAUSAL, int RW, bool PAD = false>
 __global__ __launch_bounds__(64 * RW, (D == 64 ? FA16_OCC : FA16_OCC128)) void fwd_mfma16_kernel(Params p) {
-  fwd_mfma16_body<Tag, D, CAUSAL, RW>(p);
+  fwd_mfma16_body<Tag, D, CAUSAL, RW, PAD>(p);
 }
 
-bool mfma16_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128); }
+bool mfma16_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 128 && D % 8 == 0; }
 
-template <typename Tag, int D, bool CAUSAL, int RW>
+template <typename Tag, int D, bool CAUSAL, int RW, bool PAD = false>
 static hipError_t launch16_one(const Params &p, hipStream_t s) {
   const int nQ = (p.N + RW * WM - 1) / (RW * WM);
   const size_t smem = 4 * (size_t)(D == 128 ? FA16_BN128 : BN) * D * 2;
-  auto kern = fwd_mfma16_kernel<Tag, D, CAUSAL, RW>;
+  auto kern = fwd_mfma16_kernel<Tag, D, CAUSAL, RW, PAD>;
   if (smem > 48 * 1024) {
     hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
     if (e != hipSuccess) return e;
@@ -540,6 +547,7 @@ int mfma16_waves(int D, int BH, int N, int Nk, int is_causal) {
 #ifdef FA16_FORCE_RW
   return FA16_FORCE_RW;
 #endif
+  if (D != 64 && D != 128) return 4;  // (padded head dims)
   const long long b256 = (long long)BH * ((N + 255) / 256);
   if (D == 128) return (!is_causal && Nk >= 8192 && b256 >= 1024) ? 8 : 4;
   if (!is_causal) return (Nk >= 512 && b256 >= 512) ? 8 : 4;
@@ -550,6 +558,10 @@ hipError_t launch_mfma16(const Params &p, int dtype, hipStream_t s) {
   const bool w8 = mfma16_waves(p.D, p.B * p.H, p.N, p.Nk, p.is_causal) == 8 && (p.D == 64 || !p.is_causal);
   auto go = [&](auto tag) -> hipError_t {
     using Tag = decltype(tag);
+    if (p.D != 64 && p.D != 128) {  // zero-padded rows of the next larger instantiation (four waves)
+      if (p.D < 64) return p.is_causal ? launch16_one<Tag, 64, true, 4, true>(p, s) : launch16_one<Tag, 64, false, 4, true>(p, s);
+      return p.is_causal ? launch16_one<Tag, 128, true, 4, true>(p, s) : launch16_one<Tag, 128, false, 4, true>(p, s);
+    }
     if (p.D == 64) {
       if (w8) return p.is_causal ? launch16_one<Tag, 64, true, 8>(p, s) : launch16_one<Tag, 64, false, 8>(p, s);
       return p.is_causal ? launch16_one<Tag, 64, true, 4>(p, s) : launch16_one<Tag, 64, false, 4>(p, s);

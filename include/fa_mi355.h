@@ -94,8 +94,10 @@ enum fa_status {
  *                (rows contiguous, row pitch D); 16-byte aligned, strides multiples of 8 elements (16 for fp8)
  *  lse           device pointer to B*H*N floats, contiguous [B,H,N]; may be NULL
  *  N             sequence length (queries == keys); any N >= 1
- *  D             head dim: 32, 64, 96, 128 or 256 for FA_VARIANT_MFMA (fp8 inputs: 64, 128, 256), 64 or 128 for
- *                FA_VARIANT_MFMA16 / _SPLIT2 / _FP8PV, 64 for _H64S2 / _SPLITKV, <= 128 (multiple of 4) for the scalar variants
+ *  D             head dim: 32, 64, 96, 128 or 256 for FA_VARIANT_MFMA (fp8 inputs: 64, 128, 256); any multiple of 8 up to 128 for
+ *                FA_VARIANT_MFMA16 (f16 / bf16: 64 and 128 natively, the others on zero-padded rows of the next larger one -- what
+ *                FA_VARIANT_AUTO takes for head dims such as 40, 72, 80, 112; a head must then stay below 2 GiB); 64 or 128 for
+ *                FA_VARIANT_MFMA_SPLIT2 / _FP8PV, 64 for _H64S2 / _SPLITKV, <= 128 (multiple of 4) for the scalar variants
  *  scale         softmax scale (> 0); the reference passes 1/sqrt(D) (main.mm:13)
  *  dtype/variant enums above
  *  hip_stream    hipStream_t on the current device, or NULL

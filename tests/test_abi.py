@@ -53,9 +53,12 @@ def test_support_table(fa):
             for t in ("f32", "f16", "bf16"):
                 assert fa.supported(t, v, d)
     for d in (32, 96, 256):  # scope row f3: the other head dims run on the 128-row matrix-core kernel
-        assert fa.supported("bf16", "mfma", d) and fa.supported("f16", "mfma", d) and not fa.supported("bf16", "mfma16", d)
+        assert fa.supported("bf16", "mfma", d) and fa.supported("f16", "mfma", d) and fa.supported("bf16", "mfma16", d) == (d < 128)
     assert fa.supported("fp8_e4m3", "mfma", 256) and not fa.supported("fp8_e4m3", "mfma", 32) and not fa.supported("fp8_e4m3", "mfma", 96)
     assert not fa.supported("bf16", "mfma", 48) and not fa.supported("bf16", "mfma", 512)
+    # the 16x16x32 kernel takes every multiple of 8 up to 128 (16-bit inputs): 64 / 128 natively, the others on zero-padded rows
+    assert fa.supported("bf16", "mfma16", 48) and fa.supported("f16", "mfma16", 120) and fa.supported("bf16", "auto", 80)
+    assert not fa.supported("bf16", "mfma16", 44) and not fa.supported("bf16", "mfma16", 136) and not fa.supported("fp8_e4m3", "mfma16", 48)
     assert fa.supported("fp8_e4m3", "mfma_fp8pv", 64) and fa.supported("fp8_e4m3", "mfma_fp8pv", 128) and not fa.supported("fp8_e4m3", "mfma_fp8pv", 256) and not fa.supported("bf16", "mfma_fp8pv", 64)
     assert fa.supported("bf16", "mfma_splitkv", 64) and not fa.supported("bf16", "mfma_splitkv", 128)  # head_dim 64 only since version 400
     lib = fa.load_library()
@@ -90,7 +93,8 @@ def test_bad_arguments_are_rejected_before_launch(fa):
     assert call(dtype=9) == -1
     assert call(hs=100) == -1 and b"stride" in lib.fa_last_error()
     assert call(q=P(0x1004)) == -1 and b"aligned" in lib.fa_last_error()
-    assert call(D=48) == -2 and b"no kernel" in lib.fa_last_error()
+    assert call(D=44) == -2 and b"no kernel" in lib.fa_last_error()  # (multiples of 8 up to 128 all have a kernel: padded rows)
+    assert call(D=136) == -2 and call(D=48, dtype=3) == -2  # ... 16-bit inputs only, and nothing between 128 and 256
     assert call(dtype=0, variant=4) == -2 and b"mfma" in lib.fa_last_error()
     assert call(dtype=3, variant=3) == -2  # fp8 inputs exist for the matrix-core variant only
     assert call(dtype=3, hs=128 * 64 + 8) == -1  # fp8 heads must stay 16-byte aligned

@@ -684,6 +684,40 @@ def _full_size(fa, oracle_mod, B, H, N, D, dtype, causal, heads, nrows=48, varia
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("D", [8, 16, 24, 40, 48, 56, 72, 80, 88, 104, 112, 120])
+def test_forward_any_multiple_of_eight(fa, oracle_mod, D):
+    """Head dims without a kernel of their own (scope row f3): every multiple of 8 up to 128 runs the 16x16x32 kernel's next larger
+    instantiation on zero-padded rows (csrc/fa_mfma16_kernel.hip, PAD) -- through AUTO, both 16-bit dtypes, causal and full, ragged
+    lengths with partial blocks and tiles, and through fa_fwd_ex with grouped heads and Nq != Nk."""
+    import torch
+
+    assert fa.supported("bf16", "auto", D) and fa.load_library().fa_resolve_variant_for(2, D, 1, 2, 300, 1) == fa.VARIANTS["mfma16"]
+    for dtype in ("bf16", "f16"):
+        for (B, H, N) in ((1, 2, 300), (2, 3, 129), (1, 1, 1), (1, 2, 1000)):
+            q, k, v = make_qkv(oracle_mod, B, H, N, D, dtype)
+            for causal in (False, True):
+                check(fa, oracle_mod, q, k, v, dtype, causal, "auto", tol_scale=2.0)
+    # grouped heads and a longer key sequence (bottom-right aligned mask)
+    dtype = "bf16"
+    q, _, _ = make_qkv(oracle_mod, 1, 4, 100, D, dtype)
+    _, k, v = make_qkv(oracle_mod, 1, 2, 260, D, dtype)
+    for causal in (False, True):
+        o, lse = fa.flash_attention_forward(to_dev(q, dtype), to_dev(k, dtype), to_dev(v, dtype), is_causal=causal)
+        torch.cuda.synchronize()
+        ke, ve = (np.repeat(x, 2, axis=1) for x in (k, v))
+        s_ = np.einsum("bhid,bhjd->bhij", q.astype(np.float64), ke.astype(np.float64)) / np.sqrt(D)
+        if causal:
+            i, j = np.arange(100)[:, None], np.arange(260)[None, :]
+            s_ = np.where(j <= i + 160, s_, -np.inf)
+        m_ = s_.max(-1, keepdims=True)
+        p_ = np.exp(s_ - m_)
+        o64 = np.einsum("bhij,bhjd->bhid", p_ / p_.sum(-1, keepdims=True), ve.astype(np.float64))
+        l64 = (m_ + np.log(p_.sum(-1, keepdims=True)))[..., 0]
+        assert o.shape == (1, 4, 100, D)
+        assert np.abs(o.float().cpu().numpy() - o64).max() < TOL_O[dtype] * 2
+        assert np.abs(lse.cpu().numpy() - l64).max() < lse_tol(dtype, 2, q, np.repeat(k, 2, axis=1))
+
+
 def test_mfma16_eight_wave_workgroups(fa, oracle_mod):
     """The 16x16x32 kernel runs 256-row workgroups (eight waves sharing every K / V tile) where its launch rule says so
     (csrc/fa_mfma16_kernel.hip, mfma16_waves): non-causal grids of at least 512 such workgroups, the two-round causal grids of config 3's
@@ -692,13 +726,13 @@ def test_mfma16_eight_wave_workgroups(fa, oracle_mod):
     28 tests, profiles/r04/tests_mfma16_eight_waves_forced.log.)"""
     lib = fa.load_library()
     # which instantiation AUTO launches (the kernel name carries the waves per workgroup)
-    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4096, 1).decode().endswith("64, true, 8>")    # config 3
-    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4100, 1).decode().endswith("64, true, 8>")
-    assert lib.fa_fwd_kernel_name(2, 64, 8, 16, 4096, 1).decode().endswith("64, true, 4>")    # twice the heads: four waves
-    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 1).decode().endswith("64, true, 4>")
-    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 0).decode().endswith("64, false, 8>")
-    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 8192, 0).decode().endswith("128, false, 8>")
-    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 16384, 1).decode().endswith("128, true, 4>")  # config 4's shard
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4096, 1).decode().endswith("64, true, 8, false>")    # config 3
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4100, 1).decode().endswith("64, true, 8, false>")
+    assert lib.fa_fwd_kernel_name(2, 64, 8, 16, 4096, 1).decode().endswith("64, true, 4, false>")    # twice the heads: four waves
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 1).decode().endswith("64, true, 4, false>")
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 0).decode().endswith("64, false, 8, false>")
+    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 8192, 0).decode().endswith("128, false, 8, false>")
+    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 16384, 1).decode().endswith("128, true, 4, false>")  # config 4's shard
     _full_size(fa, oracle_mod, 1, 128, 1000, 64, "bf16", False, heads=[(0, 0), (0, 127)], variant="mfma16")   # 512 workgroups of 256 rows, ragged
     _full_size(fa, oracle_mod, 4, 16, 4100, 64, "f16", True, heads=[(0, 0), (3, 15)], variant="mfma16")       # 1088 workgroups, causal, ragged
     _full_size(fa, oracle_mod, 4, 16, 2304, 64, "bf16", False, heads=[(1, 7)], variant="auto")                # AUTO's non-causal route

@@ -1,7 +1,5 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
-tail -3 gpurun_out/gpu_tests_full.log
-timeout -k 10 1500 bash tools/collect_profiles.sh r04c > gpurun_out/collect_r04c.log 2>&1 || { tail -30 gpurun_out/collect_r04c.log; exit 1; }
-tail -32 gpurun_out/collect_r04c.log
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "any_multiple or eight_wave or auto_routes" > gpurun_out/pad_tests.log 2>&1 || { tail -40 gpurun_out/pad_tests.log; exit 1; }
+tail -3 gpurun_out/pad_tests.log
