@@ -71,7 +71,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 #endif
 // Workgroups per CU the kernels are compiled for: three at head_dim 64 (register cap 168, 32-34 KiB of LDS), two at 128
 // (cap 256, 64-66 KiB). Round 3 first ran two / one (205-214 registers): see bwd_dq_kernel for what brought them down.
-constexpr int bwd_occ(int D) { return D == 64 ? 3 : 2; }
+constexpr int bwd_occ(int D) { return D == 64 ? 3 : D == 128 ? 2 : 1; }  // (head_dim 256: one workgroup per CU, 512 registers, 128 KiB of LDS)
 // 64-row sub-tiles per staged tile: one barrier and one staging pass per SUB * 64 keys (dQ) / queries (dK, dV). 2 paid while
 // one workgroup per CU exposed every barrier (+16 % at head_dim 128 then); at the occupancy above 1 is faster and is what
 // fits the LDS (profiles/r03/ab_bwd_dq_per_half.log).
@@ -218,11 +218,14 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dq_kernel(BwdParams 
 
   constexpr bool DMA = FA_BWD_DMA != 0;
   static_assert(DMA || !PAD, "padded head dims are staged by LDS-DMA only");
-  const unsigned dvo = PAD ? dma_off_pad(wave, lane) : dma_off(wave, lane);
+  const unsigned dvo_ = PAD ? dma_off_pad(wave, lane) : dma_off(wave, lane);
+  // (head_dim 256: a piece is 2 rows and a wave's pieces are 8 rows apart, half the swizzle's period: odd pieces flip bit 1 of the chunk)
+  const unsigned dvo1 = dvo_ ^ 32u;
   // tile t -> buffer buf by LDS-DMA (hipcc does not count these loads: stage_write waits vmcnt(0))
   auto stage_dma = [&](int t, int buf) {
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
+      const unsigned dvo = (BD == 256 && (j & 1)) ? dvo1 : dvo_;
       const unsigned soff = PAD ? (unsigned)(t * BT + j * 4 * RPP) * GRB : (unsigned)t * STILE + j * 4096;
       const unsigned lk = (unsigned)(__UINTPTR_TYPE__)KU + buf * STILE + (wave + 4 * j) * 1024;
       const unsigned lv = (unsigned)(__UINTPTR_TYPE__)VR + buf * STILE + (wave + 4 * j) * 1024;
@@ -460,11 +463,14 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
   };
   constexpr bool DMA = FA_BWD_DMA != 0;
   static_assert(DMA || !PAD, "padded head dims are staged by LDS-DMA only");
-  const unsigned dvo = PAD ? dma_off_pad(wave, lane) : dma_off(wave, lane);
+  const unsigned dvo_ = PAD ? dma_off_pad(wave, lane) : dma_off(wave, lane);
+  // (head_dim 256: a piece is 2 rows and a wave's pieces are 8 rows apart, half the swizzle's period: odd pieces flip bit 1 of the chunk)
+  const unsigned dvo1 = dvo_ ^ 32u;
   auto stage_load = [&](int t, int buf) {
     if constexpr (DMA) {  // (hipcc does not count these loads: stage_write waits vmcnt(0))
 #pragma unroll
       for (int j = 0; j < NPW; ++j) {
+        const unsigned dvo = (BD == 256 && (j & 1)) ? dvo1 : dvo_;
         const unsigned soff = PAD ? (unsigned)(t * BT + j * 4 * RPP) * GRB : (unsigned)t * STILE + j * 4096;
         const unsigned lq = (unsigned)(__UINTPTR_TYPE__)QU + buf * STILE + (wave + 4 * j) * 1024;
         const unsigned lo = (unsigned)(__UINTPTR_TYPE__)OU + buf * STILE + (wave + 4 * j) * 1024;
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
           }
         }
         {
-          constexpr int NF = 2 * BKS, LA = BD == 128 ? FA_BWD_KV128_LA : FA_BWD_LA;
+          constexpr int NF = 2 * BKS, LA = BD >= 128 ? FA_BWD_KV128_LA : FA_BWD_LA;
           vec8 fr[NF];
           auto fread = [&](auto fc) {  // f = (ks, which): which 0 = Q row fragment, 1 = dO row fragment
             constexpr int f = decltype(fc)::value;
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
         }
         // dV / dK fragments of this half (step j = (st, db, which): which 0 = dO^T fragment -> dV, 1 = Q^T fragment -> dK) are
         // read LA2 steps ahead of their MFMA, the first ones before the P / dS arithmetic (they do not depend on it)
-        constexpr int NJ = 4 * BDB, LA2 = BD == 128 ? FA_BWD_KV128_LA2 : FA_BWD_LA2, TV = BD == 64 ? 4 : 2;
+        constexpr int NJ = 4 * BDB, LA2 = BD >= 128 ? FA_BWD_KV128_LA2 : FA_BWD_LA2, TV = BD == 64 ? 4 : 2;
         s16x4 tlo[NJ], thi[NJ];
         auto tread = [&](auto jc) {
           constexpr int j = decltype(jc)::value, jj = j / 2, R0 = 32 * qb + 16 * (jj / BDB), db = jj % BDB;
@@ -666,7 +672,7 @@ __global__ __launch_bounds__(NTHREADS, bwd_occ(D)) void bwd_dkdv_kernel(BwdParam
 // ---------------------------------------------------------------------------
 bool bwd_supported(int dtype, int D) {
   if (dtype == FA_DTYPE_FP8_E4M3) return D >= 16 && D <= 128 && D % 16 == 0;  // (rows of whole 16-byte chunks: the widening pass)
-  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 128 && D % 8 == 0;
+  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && ((D >= 8 && D <= 128 && D % 8 == 0) || D == 256);
 }
 
 // e4m3 inputs (the forward's config-5 family): Q, K, V are widened to bf16 -- exactly: every e4m3 value is a bf16 value -- into the
@@ -728,6 +734,7 @@ template <typename Tag>
 static hipError_t launch_bwd_dt(const BwdParams &p, hipStream_t s) {
   if (p.D == 64) return p.is_causal ? launch_bwd_one<Tag, 64, true, false>(p, s) : launch_bwd_one<Tag, 64, false, false>(p, s);
   if (p.D == 128) return p.is_causal ? launch_bwd_one<Tag, 128, true, false>(p, s) : launch_bwd_one<Tag, 128, false, false>(p, s);
+  if (p.D == 256) return p.is_causal ? launch_bwd_one<Tag, 256, true, false>(p, s) : launch_bwd_one<Tag, 256, false, false>(p, s);
   if (p.D < 64) return p.is_causal ? launch_bwd_one<Tag, 64, true, true>(p, s) : launch_bwd_one<Tag, 64, false, true>(p, s);
   return p.is_causal ? launch_bwd_one<Tag, 128, true, true>(p, s) : launch_bwd_one<Tag, 128, false, true>(p, s);
 }

@@ -192,7 +192,8 @@ int fa_fwd_decode_supported(int dtype, int D, int Hq, int Hkv, int Nq);
  * like the inputs (element (b,h,i,d) at b*batch_stride + h*head_stride + i*D + d, fp32).
  * `workspace` is caller-owned scratch of fa_bwd_workspace_bytes(B,H,N) bytes (device memory).
  * dtype F16 or BF16 (FP8_E4M3: see fa_bwd_workspace_bytes_ex); D = 64 (the reference's, kernels.metal:905-1265) or 128 natively, any other multiple of 8 up to 128 (32, 96, ...)
- * through the next larger kernel on zero-padded rows (same results per real column; a head must then stay below 2 GiB). D = 256: none.
+ * through the next larger kernel on zero-padded rows (same results per real column; a head must then stay below 2 GiB). D = 256: its own
+ * instantiation (one workgroup per CU, f16 / bf16 only).
  */
 int fa_bwd(const void *q, const void *k, const void *v, const void *o, const void *d_o, const float *lse,
            float *dq, float *dk, float *dv, void *workspace,

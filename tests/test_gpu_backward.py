@@ -43,7 +43,7 @@ def rel(a, ref):
     return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-4)
 
 
-@pytest.mark.parametrize("D", [32, 64, 96, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_backward_vs_oracle(fa, oracle_mod, dtype, causal, D):
@@ -57,7 +57,7 @@ def test_backward_vs_oracle(fa, oracle_mod, dtype, causal, D):
             assert rel(g, ref) < TOL[dtype], (name, dtype, causal, B, H, N, rel(g, ref))
 
 
-@pytest.mark.parametrize("D", [32, 64, 96, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
 @pytest.mark.parametrize("causal", [False, True])
 def test_backward_grouped_query_heads(fa, oracle_mod, causal, D):
     """fa_bwd_ex (scope rows f1 + f3): query head h reads key/value head h // G; dK / dV of a key head are the sums over its
@@ -122,7 +122,7 @@ def rect_reference(q, k, v, do, causal):
     return dq, dk.reshape(B, Hkv, G, Nk, D).sum(2), dv.reshape(B, Hkv, G, Nk, D).sum(2)
 
 
-@pytest.mark.parametrize("D", [32, 64, 96, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
 @pytest.mark.parametrize("causal", [False, True])
 def test_backward_rectangular(fa, oracle_mod, causal, D):
     """fa_bwd_ex with Nq != Nk (the counterpart of fa_fwd_ex): cross-attention shapes, and bottom-right aligned causal masks."""
@@ -153,7 +153,7 @@ def test_backward_rectangular(fa, oracle_mod, causal, D):
         assert e.value.status == -2
 
 
-@pytest.mark.parametrize("D", [32, 64, 96, 128])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
 def test_backward_partial_last_key_tile_with_strongly_negative_scores(fa, oracle_mod, D):
     """Non-causal, Nk % 64 != 0, every score strongly negative (k = -8 q direction, f16): lse << 0, so a key slot past Nk -- whose
     K / V rows arrive as zeros -- would give P = exp(-lse) and overflow the cast of dS (inf x 0 = NaN in the whole dQ row) unless the
@@ -257,7 +257,7 @@ def test_backward_errors(fa):
     import torch
 
     lse = torch.zeros(1, 1, 128, device="cuda")
-    for D in (256, 36, 136):  # the backward covers multiples of 8 up to 128 (the forward also has 256)
+    for D in (36, 136, 512):  # the backward covers multiples of 8 up to 128, and 256
         x = torch.zeros(1, 1, 128, D, dtype=torch.bfloat16, device="cuda")
         with pytest.raises(fa.FaError) as e:
             fa.flash_attention_backward(x, x, x, x, x, lse)
@@ -363,10 +363,10 @@ def test_torch_op_autograd_matches_sdpa(fa, oracle_mod, dtype, causal):
         err = (g.double() - g64).abs().max().item()
         assert err < tol * g64.abs().max().item(), (name, err, g64.abs().max().item())
     # shapes without a backward kernel raise instead of handing back a silent zero gradient
-    q256 = torch.zeros(1, 1, 64, 256, dtype=torch.bfloat16, device="cuda", requires_grad=True)  # the forward has head_dim 256, the backward not
-    o256, _ = torch.ops.fa_mi355.attention_forward(q256, q256.detach(), q256.detach(), False, 0.0)
+    q32 = torch.zeros(1, 1, 64, 64, dtype=torch.float32, device="cuda", requires_grad=True)  # fp32 inputs: a forward (scalar kernels), no backward
+    o32, _ = torch.ops.fa_mi355.attention_forward(q32, q32.detach(), q32.detach(), False, 0.0)
     with pytest.raises(Exception):
-        o256.float().sum().backward()
+        o32.float().sum().backward()
     # head_dim 96 (zero-padded rows of the 128 kernel) through autograd
     q96, k96, v96 = (to_dev(x, dtype).requires_grad_(True) for x in make_qkv(oracle_mod, 1, 2, 130, 96, dtype))
     o96, _ = torch.ops.fa_mi355.attention_forward(q96, k96, v96, causal, 0.0)
