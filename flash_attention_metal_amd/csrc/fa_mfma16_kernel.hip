@@ -55,6 +55,9 @@
 #ifndef FA16_OCC128
 #define FA16_OCC128 2  // workgroups per CU the head_dim-128 kernel is compiled for (2: 256 registers, 3: 168)
 #endif
+#ifndef FA16_SUB8
+#define FA16_SUB8 1  // tiles per staged unit (barrier) of the eight-wave head_dim-64 instantiation: 1, or 2 (64 KiB of LDS)
+#endif
 #ifndef FA16_OCC
 #define FA16_OCC 4  // workgroups per CU the head_dim-64 kernel is compiled for (128 registers)
 #endif
@@ -83,7 +86,7 @@ __device__ __forceinline__ float xlane(float x, int mask) { return __shfl_xor(x,
 // in global memory, the LDS images and register fragments have the kernel's pitch, and every 16-byte chunk at or past column p.D is
 // fetched from an offset outside the buffer descriptor's range, which reads as zeros for register loads and LDS-DMA alike. The padding
 // adds 0 to every score and its O columns are never stored.
-template <typename Tag, int D, bool CAUSAL, int RW, bool PAD>
+template <typename Tag, int D, bool CAUSAL, int RW, bool PAD, int SUB>
 __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   using M = MT16<Tag>;
   using vec8 = typename M::vec8;
@@ -101,8 +104,10 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
-  lds_char *Kbuf = smem;             // [2][BN][RB], chunks swizzled
-  lds_char *Vbuf = smem + 2 * TILE;  // [2][BN][RB], chunks swizzled
+  // SUB = 2: a staged unit is a PAIR of tiles (one barrier and one staging pass per 128 keys; slots 2 buf + sub) -- affordable where the
+  // workgroups are 256 rows high (two per CU: 2 x 64 KiB of LDS)
+  lds_char *Kbuf = smem;                   // [2 SUB][BN][RB], chunks swizzled
+  lds_char *Vbuf = smem + 2 * SUB * TILE;  // [2 SUB][BN][RB], chunks swizzled
 
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -217,6 +222,9 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   }
 
   stage_dma(0, 0);
+  if constexpr (SUB == 2) {
+    if (1 < nT) stage_dma(1, 1);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // Q~ = round(c.Q), once per block; retire the Q loads HERE (hipcc otherwise carries them into the loop as "possibly pending")
 #pragma unroll
@@ -365,7 +373,6 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
     constexpr int buf = decltype(bufc)::value;
     constexpr bool FIRST = decltype(firstc)::value;
     const int kv0 = t * BNK;
-    if (t + 1 < nT) stage_dma(t + 1, buf ^ 1);  // the next tile, in flight under this tile's MFMAs
 
     // whole-tile skip per wave (kernels.metal:682 with Br = 32)
     // (non-causal: an always-true scalar hipcc cannot see through -- with the tile body unconditional it schedules across the
@@ -460,13 +467,25 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
         break;
       }
     }
-    if (t + 1 < nT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this tile have landed
+  };
+  // one staged unit (SUB tiles from tile t0 on, in the slots of buffer `buf`): the next unit's tiles go into the other buffer first, in
+  // flight under this unit's MFMAs; one wait + barrier at its end
+  auto unit = [&](auto bufc, auto firstc, const int t0) {
+    constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+    for (int sub = 0; sub < SUB; ++sub)
+      if (t0 + SUB + sub < nT) stage_dma(t0 + SUB + sub, (buf ^ 1) * SUB + sub);
+    tile(std::integral_constant<int, buf * SUB>{}, firstc, t0);
+    if constexpr (SUB == 2) {
+      if (t0 + 1 < nT) tile(std::integral_constant<int, buf * SUB + 1>{}, std::false_type{}, t0 + 1);
+    }
+    if (t0 + SUB < nT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued at the top of this unit have landed
     __syncthreads();
   };
-  tile(std::integral_constant<int, 0>{}, std::true_type{}, 0);
-  for (int t = 1; t < nT; t += 2) {
-    tile(std::integral_constant<int, 1>{}, std::false_type{}, t);
-    if (t + 1 < nT) tile(std::integral_constant<int, 0>{}, std::false_type{}, t + 1);
+  unit(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+  for (int t = SUB; t < nT; t += 2 * SUB) {
+    unit(std::integral_constant<int, 1>{}, std::false_type{}, t);
+    if (t + SUB < nT) unit(std::integral_constant<int, 0>{}, std::false_type{}, t + SUB);
   }
 
   // ---- epilogue: normalise, LSE, O tile -> LDS -> coalesced 16-byte stores
@@ -508,18 +527,18 @@ __device__ __forceinline__ void fwd_mfma16_body(const Params &p) {
   }
 }
 
-template <typename Tag, int D, bool CAUSAL, int RW, bool PAD = false>
+template <typename Tag, int D, bool CAUSAL, int RW, bool PAD = false, int SUB = 1>
 __global__ __launch_bounds__(64 * RW, (D == 64 ? FA16_OCC : FA16_OCC128)) void fwd_mfma16_kernel(Params p) {
-  fwd_mfma16_body<Tag, D, CAUSAL, RW, PAD>(p);
+  fwd_mfma16_body<Tag, D, CAUSAL, RW, PAD, SUB>(p);
 }
 
 bool mfma16_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && D >= 8 && D <= 128 && D % 8 == 0; }
 
-template <typename Tag, int D, bool CAUSAL, int RW, bool PAD = false>
+template <typename Tag, int D, bool CAUSAL, int RW, bool PAD = false, int SUB = 1>
 static hipError_t launch16_one(const Params &p, hipStream_t s) {
   const int nQ = (p.N + RW * WM - 1) / (RW * WM);
-  const size_t smem = 4 * (size_t)(D == 128 ? FA16_BN128 : BN) * D * 2;
-  auto kern = fwd_mfma16_kernel<Tag, D, CAUSAL, RW, PAD>;
+  const size_t smem = 4 * SUB * (size_t)(D == 128 ? FA16_BN128 : BN) * D * 2;
+  auto kern = fwd_mfma16_kernel<Tag, D, CAUSAL, RW, PAD, SUB>;
   if (smem > 48 * 1024) {
     hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem);
     if (e != hipSuccess) return e;
@@ -563,7 +582,7 @@ hipError_t launch_mfma16(const Params &p, int dtype, hipStream_t s) {
       return p.is_causal ? launch16_one<Tag, 128, true, 4, true>(p, s) : launch16_one<Tag, 128, false, 4, true>(p, s);
     }
     if (p.D == 64) {
-      if (w8) return p.is_causal ? launch16_one<Tag, 64, true, 8>(p, s) : launch16_one<Tag, 64, false, 8>(p, s);
+      if (w8) return p.is_causal ? launch16_one<Tag, 64, true, 8, false, FA16_SUB8>(p, s) : launch16_one<Tag, 64, false, 8, false, FA16_SUB8>(p, s);
       return p.is_causal ? launch16_one<Tag, 64, true, 4>(p, s) : launch16_one<Tag, 64, false, 4>(p, s);
     }
     if (p.D == 128) {

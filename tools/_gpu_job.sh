@@ -1,5 +1,6 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_backward.py -x -q > gpurun_out/bwd_tests.log 2>&1 || { tail -40 gpurun_out/bwd_tests.log; exit 1; }
-tail -3 gpurun_out/bwd_tests.log
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+timeout -k 10 900 python tools/ab.py $L:10 tools/ab/lib_sub2.so:10 --shapes c3,nc4k,nc2k,c3f16,c5k --rounds 10 --iters 12 --warm-ms 600 > gpurun_out/ab_sub2.log 2>&1
+cat gpurun_out/ab_sub2.log
