@@ -737,6 +737,24 @@ def test_mfma16_eight_wave_workgroups(fa, oracle_mod):
     _full_size(fa, oracle_mod, 4, 16, 4100, 64, "f16", True, heads=[(0, 0), (3, 15)], variant="mfma16")       # 1088 workgroups, causal, ragged
     _full_size(fa, oracle_mod, 4, 16, 2304, 64, "bf16", False, heads=[(1, 7)], variant="auto")                # AUTO's non-causal route
     _full_size(fa, oracle_mod, 1, 32, 8192, 128, "bf16", False, heads=[(0, 5)], nrows=24, variant="mfma16")   # head_dim 128
+    # grouped heads and Nq != Nk on the eight-wave form (fa_fwd_ex: 256 query heads on 32 key heads, 500 queries x 2000 keys, no mask)
+    import torch
+
+    g = torch.Generator(device="cuda").manual_seed(77)
+    q = torch.rand(1, 256, 500, 64, generator=g, device="cuda").mul_(2).sub_(1).to(torch.bfloat16)
+    k, v = (torch.rand(1, 32, 2000, 64, generator=g, device="cuda").mul_(2).sub_(1).to(torch.bfloat16) for _ in range(2))
+    o, lse = fa.flash_attention_forward(q, k, v, is_causal=False, variant="mfma16")
+    torch.cuda.synchronize()
+    rows = np.array([0, 1, 31, 32, 127, 128, 255, 256, 257, 383, 384, 499], dtype=np.int32)
+    for h in (0, 7, 8, 255):
+        qh, kh, vh = q[0, h].float().cpu().numpy(), k[0, h // 8].float().cpu().numpy(), v[0, h // 8].float().cpu().numpy()
+        s_ = (qh[rows].astype(np.float64) @ kh.astype(np.float64).T) / 8.0
+        m_ = s_.max(-1, keepdims=True)
+        p_ = np.exp(s_ - m_)
+        o64 = (p_ / p_.sum(-1, keepdims=True)) @ vh.astype(np.float64)
+        l64 = (m_ + np.log(p_.sum(-1, keepdims=True)))[:, 0]
+        assert np.abs(o[0, h].float().cpu().numpy()[rows] - o64).max() < TOL_O["bf16"], h
+        assert np.abs(lse[0, h].cpu().numpy()[rows] - l64).max() < lse_tol("bf16", 2, qh, kh), h
 
 
 @pytest.mark.parametrize("variant", ["auto", "tiled_v2", "mfma", "mfma_splitkv", "mfma_split2", "mfma_exact", "mfma_h64s2", "mfma16"])
