@@ -1,5 +1,6 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "eight_wave" > gpurun_out/t8.log 2>&1 || { tail -40 gpurun_out/t8.log; exit 1; }
-tail -3 gpurun_out/t8.log
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+timeout -k 10 600 python tools/ab.py $L:11 tools/ab/lib_occ3.so:11 tools/ab/lib_hilo3.so:11 --shapes c5,c5 --rounds 8 --iters 10 --warm-ms 500 > gpurun_out/ab_fp8_hilo3.log 2>&1
+cat gpurun_out/ab_fp8_hilo3.log
