@@ -545,6 +545,9 @@ static hipError_t launch16_one(const Params &p, hipStream_t s) {
   }
   Params pp = p;
   pp.head_group = causal_head_group(p, D, 2);
+#ifdef FA16_FORCE_HEAD_GROUP  // scheduling experiments only (tools/ab.py arms): never defined in the shipped library
+  pp.head_group = FA16_FORCE_HEAD_GROUP;
+#endif
   set_block_divisors(pp, nQ, pp.head_group);
   (void)hipGetLastError();  // do not report an older sticky error as this launch's
   hipLaunchKernelGGL(kern, dim3(nQ * p.B * p.H), dim3(64 * RW), smem, s, pp);
