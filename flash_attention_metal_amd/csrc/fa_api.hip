@@ -147,7 +147,8 @@ const char *fa_fwd_kernel_name(int dtype, int D, int B, int H, int N, int is_cau
     case FA_VARIANT_MFMA_SPLIT2: snprintf(name, sizeof(name), "fa::fwd_mfma_split2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA_H64S2: snprintf(name, sizeof(name), "fa::fwd_mfma_h64s2_kernel<%s, %d, %s>", tag, D, c); break;
     case FA_VARIANT_MFMA16:
-      snprintf(name, sizeof(name), "fa::fwd_mfma16_kernel<%s, %d, %s, %d, %s>", tag, (D == 64 || D == 128) ? D : (D < 64 ? 64 : 128), c,
+      // (template arguments as rocprofv3 prints them: dtype, head dim of the instantiation, causal, waves per workgroup, padded rows, tiles per barrier)
+      snprintf(name, sizeof(name), "fa::fwd_mfma16_kernel<%s, %d, %s, %d, %s, 1>", tag, (D == 64 || D == 128) ? D : (D < 64 ? 64 : 128), c,
                fa::mfma16_waves(D, B * H, N, N, is_causal), (D == 64 || D == 128) ? "false" : "true");
       break;
     case FA_VARIANT_MFMA_FP8PV: snprintf(name, sizeof(name), "fa::fwd_fp8_kernel<%d, %s>", D, c); break;

@@ -541,7 +541,7 @@ def test_torch_custom_op_matches_sdpa(fa, oracle_mod):
 def test_error_behaviour_on_device(fa):
     import torch
 
-    x = torch.zeros(1, 1, 128, 48, dtype=torch.bfloat16, device="cuda")
+    x = torch.zeros(1, 1, 128, 136, dtype=torch.bfloat16, device="cuda")  # (every multiple of 8 up to 128 has a kernel; between 128 and 256 none)
     with pytest.raises(fa.FaError) as e:
         fa.flash_attention_forward(x, x, x)
     assert e.value.status == -2
@@ -726,13 +726,13 @@ def test_mfma16_eight_wave_workgroups(fa, oracle_mod):
     28 tests, profiles/r04/tests_mfma16_eight_waves_forced.log.)"""
     lib = fa.load_library()
     # which instantiation AUTO launches (the kernel name carries the waves per workgroup)
-    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4096, 1).decode().endswith("64, true, 8, false>")    # config 3
-    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4100, 1).decode().endswith("64, true, 8, false>")
-    assert lib.fa_fwd_kernel_name(2, 64, 8, 16, 4096, 1).decode().endswith("64, true, 4, false>")    # twice the heads: four waves
-    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 1).decode().endswith("64, true, 4, false>")
-    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 0).decode().endswith("64, false, 8, false>")
-    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 8192, 0).decode().endswith("128, false, 8, false>")
-    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 16384, 1).decode().endswith("128, true, 4, false>")  # config 4's shard
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4096, 1).decode().endswith("64, true, 8, false, 1>")    # config 3
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 4100, 1).decode().endswith("64, true, 8, false, 1>")
+    assert lib.fa_fwd_kernel_name(2, 64, 8, 16, 4096, 1).decode().endswith("64, true, 4, false, 1>")    # twice the heads: four waves
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 1).decode().endswith("64, true, 4, false, 1>")
+    assert lib.fa_fwd_kernel_name(2, 64, 4, 16, 2048, 0).decode().endswith("64, false, 8, false, 1>")
+    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 8192, 0).decode().endswith("128, false, 8, false, 1>")
+    assert lib.fa_fwd_kernel_name(2, 128, 1, 32, 16384, 1).decode().endswith("128, true, 4, false, 1>")  # config 4's shard
     _full_size(fa, oracle_mod, 1, 128, 1000, 64, "bf16", False, heads=[(0, 0), (0, 127)], variant="mfma16")   # 512 workgroups of 256 rows, ragged
     _full_size(fa, oracle_mod, 4, 16, 4100, 64, "f16", True, heads=[(0, 0), (3, 15)], variant="mfma16")       # 1088 workgroups, causal, ragged
     _full_size(fa, oracle_mod, 4, 16, 2304, 64, "bf16", False, heads=[(1, 7)], variant="auto")                # AUTO's non-causal route

@@ -1,6 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-L=flash_attention_metal_amd/csrc/libfa_mi355.so
-timeout -k 10 1000 python tools/ab.py $L:10 tools/ab/lib_hg32.so:10 tools/ab/lib_hg16.so:10 --shapes c3,c8k,c3x2 --rounds 8 --iters 10 --warm-ms 600 > gpurun_out/ab_hg_warm.log 2>&1
-cat gpurun_out/ab_hg_warm.log
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
+tail -3 gpurun_out/gpu_tests_full.log
+timeout -k 10 1500 bash tools/collect_profiles.sh r04f > gpurun_out/collect_r04f.log 2>&1 || { tail -30 gpurun_out/collect_r04f.log; exit 1; }
+tail -30 gpurun_out/collect_r04f.log
