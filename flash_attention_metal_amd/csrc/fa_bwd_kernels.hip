@@ -17,8 +17,9 @@
 //
 // S and dP are computed twice (7 matrix products instead of 5) in exchange for deterministic,
 // atomic-free, bitwise reproducible gradients. (The single-pass 5-product form sums dQ across key blocks with float
-// atomics: at head_dim 64 that is 570 MB of adds for BASELINE config 3's shape, 440 us at the chip's 1.3 TB/s atomic
-// rate (MI355X_MICROARCH.md, Global float atomics) -- as long as both kernels here together.)
+// atomics: at head_dim 64 that is 570 MB of adds for BASELINE config 3's shape with 256 keys per workgroup, 436 us MEASURED
+// (tools/probes/probe_dq_atomic_floor.hip: 1.31-1.34 TB/s, MI355X_MICROARCH.md, Global float atomics) -- as long as both kernels here
+// together; 861 us vs ~850 at head_dim 128: the bytes per FLOP do not depend on the head dim. DESIGN 4.6b.)
 // Round 3: the row constants ride in the accumulators (cdna guide, attention backward): the operand held in registers is
 // pre-scaled by scale*log2(e) (Q~ in the dQ kernel -- bit for bit the forward's operand --, K~ in the dK/dV kernel) and the
 // score chains start from -LSE*log2(e), the dP chains from -delta, so P = exp2(S') and dS = P * dP' are one
