@@ -325,10 +325,11 @@ int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *l
     return fail(FA_ERR_UNSUPPORTED, "fa_fwd_decode: causal needs Nk >= Nq (bottom-right alignment would leave empty rows)");
   if (!(scale > 0.0f)) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: scale=%g must be > 0", (double)scale);
   if (!fa_fwd_decode_supported(dtype, D, Hq, Hkv, Nq))
-    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_decode: needs f16 / bf16, D = 64 | 128 and (Hq / Hkv) * Nq <= 32 packed query rows; got dtype=%s D=%d "
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_decode: needs f16 / bf16 / fp8_e4m3, D = 64 | 128 and (Hq / Hkv) * Nq <= 32 packed query rows; got dtype=%s D=%d "
                 "Hq=%d Hkv=%d Nq=%d (use fa_fwd_ex)", fa_dtype_name(dtype), D, Hq, Hkv, Nq);
-  if (q_head_stride < (long long)Nq * D || kv_head_stride < (long long)Nk * D || (q_batch_stride % 8) || (q_head_stride % 8) ||
-      (kv_batch_stride % 8) || (kv_head_stride % 8) || q_batch_stride < 0 || kv_batch_stride < 0 ||
+  const int dsm = dtype == FA_DTYPE_FP8_E4M3 ? 16 : 8;  // keeps every head 16-byte aligned
+  if (q_head_stride < (long long)Nq * D || kv_head_stride < (long long)Nk * D || (q_batch_stride % dsm) || (q_head_stride % dsm) ||
+      (kv_batch_stride % dsm) || (kv_head_stride % dsm) || q_batch_stride < 0 || kv_batch_stride < 0 ||
       (Hq > 1 && B > 1 && q_batch_stride < q_head_stride) || (Hkv > 1 && B > 1 && kv_batch_stride < kv_head_stride))
     return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: bad strides");
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) & 15)
@@ -343,7 +344,7 @@ int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *l
   p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
   p.q_bs = q_batch_stride; p.q_hs = q_head_stride; p.kv_bs = kv_batch_stride; p.kv_hs = kv_head_stride;
   p.is_causal = is_causal ? 1 : 0;
-  p.S = fa::decode_splits(B, Hkv, Nk, D);
+  p.S = fa::decode_splits(B, Hkv, Nk, D, dtype == FA_DTYPE_FP8_E4M3);
   const hipError_t e = fa::launch_decode(p, D, dtype, (hipStream_t)hip_stream);
   if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_fwd_decode: launch failed: %s", hipGetErrorString(e));
   return FA_OK;

@@ -83,7 +83,7 @@ hipError_t launch_splitkv(const Params &p, int dtype, hipStream_t s);
 
 hipError_t launch_decode(const DecodeParams &p, int D, int dtype, hipStream_t s);
 bool decode_supported(int dtype, int D);
-int decode_splits(int B, int Hkv, int Nk, int D);
+int decode_splits(int B, int Hkv, int Nk, int D, int kv8);  // kv8: e4m3 inputs (one LDS image per item: twice the items per CU)
 long long decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, int D);
 bool naive_supported(int dtype, int D);
 bool tiled_supported(int dtype, int D);

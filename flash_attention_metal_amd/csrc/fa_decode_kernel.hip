@@ -14,6 +14,10 @@
 //   * each item writes its partial (O . l, m, l) to a caller-owned workspace; a second launch combines the S partials of a row by
 //     their maxima: M = max m_s, l = sum l_s 2^(m_s - M), O = sum O_s 2^(m_s - M) / l, LSE = (M + log2 l) ln 2.
 // The library allocates nothing (C-ABI): the workspace size comes from fa_fwd_decode_workspace_bytes().
+// e4m3 inputs (KV8; dtype FA_DTYPE_FP8_E4M3: Q, K, V e4m3 as in fa_fwd's config-5 family, O bf16): HALF the bytes of the stream this
+// path is bound by. K and V tiles travel global -> registers (16 e4m3 per lane and load, the next tile's loads in flight under this
+// tile's arithmetic) -> widened EXACTLY to bf16 -> the same swizzled LDS images, so everything behind the staging is the bf16 kernel
+// bit for bit (results equal those of the bf16 path on the widened tensors). The widening is VALU work this path has to spare.
 #include <stdlib.h>
 
 #include <algorithm>
@@ -37,7 +41,22 @@ template <> struct MD16<F16> {
 };
 
 // item (b, hkv, s): rows r = gi * Nq + iq of the packed block (gi: query head within the group), keys of tiles [t0, t1)
-template <typename Tag, int D, int QT, bool CAUSAL>
+// 8 e4m3 (two dwords) -> 8 bf16 (four dwords = one 16-byte chunk): exact (bf16 = the upper half of the fp32 pattern)
+__device__ __forceinline__ u32x4 widen8(unsigned w0, unsigned w1) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  unsigned r[4];
+  const unsigned w[2] = {w0, w1};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], true);
+    const float a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];  // (scalar temporaries: bit_cast on a vector element expression reads element 0)
+    r[2 * j] = (__builtin_bit_cast(unsigned, a0) >> 16) | (__builtin_bit_cast(unsigned, a1) & 0xffff0000u);
+    r[2 * j + 1] = (__builtin_bit_cast(unsigned, b0) >> 16) | (__builtin_bit_cast(unsigned, b1) & 0xffff0000u);
+  }
+  return u32x4{r[0], r[1], r[2], r[3]};
+}
+
+template <typename Tag, int D, int QT, bool CAUSAL, bool KV8>
 __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
   using M = MD16<Tag>;
   using vec8 = typename M::vec8;
@@ -53,7 +72,7 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
-  lds_char *Kbuf = smem, *Vbuf = smem + 2 * TILE;
+  lds_char *Kbuf = smem, *Vbuf = smem + (KV8 ? 1 : 2) * TILE;
 
   const int lane = threadIdx.x;
   const int c = lane & 15, g = lane >> 4;
@@ -66,9 +85,10 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
   const int t0 = (int)((long long)s * nT / S), t1 = (int)((long long)(s + 1) * nT / S);
 
   const long long base_kv = (long long)b * p.kv_bs + (long long)hkv * p.kv_hs;
-  const unsigned kv_bytes = (unsigned)p.Nk * RB;
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.k + base_kv * 2), 0, kv_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.v + base_kv * 2), 0, kv_bytes, 0x00020000);
+  constexpr int EB = KV8 ? 1 : 2;  // bytes per input element
+  const unsigned kv_bytes = (unsigned)p.Nk * D * EB;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.k + base_kv * EB), 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)p.v + base_kv * EB), 0, kv_bytes, 0x00020000);
 
   // ---- Q fragments: lane (c, g) holds row r = 16qt + c of the packed block, elements 32ks + 8g .. +7; pre-scaled Q~ = round(c.Q)
   const float c2 = p.scale * 1.4426950408889634f;
@@ -80,11 +100,20 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
     const int gi = r / p.Nq, iq = r - gi * p.Nq;
     const bool valid = r < R;
     rlim[qt] = (CAUSAL && valid) ? iq + coff : p.Nk - 1;
-    const elem *qp = (const elem *)p.q + (long long)b * p.q_bs + (long long)(hkv * G + gi) * p.q_hs + (long long)iq * D;
+    const long long qoff = (long long)b * p.q_bs + (long long)(hkv * G + gi) * p.q_hs + (long long)iq * D;
+    const elem *qp = (const elem *)p.q + qoff;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       u32x4 t = {0u, 0u, 0u, 0u};
-      if (valid) t = *reinterpret_cast<const u32x4 *>(qp + 32 * ks + 8 * g);
+      if constexpr (KV8) {  // 8 e4m3 = 8 bytes, widened exactly
+        if (valid) {
+          const u32x2 t8 = *reinterpret_cast<const u32x2 *>((const char *)p.q + qoff + 32 * ks + 8 * g);
+          const unsigned w0 = t8[0], w1 = t8[1];
+          t = widen8(w0, w1);
+        }
+      } else {
+        if (valid) t = *reinterpret_cast<const u32x4 *>(qp + 32 * ks + 8 * g);
+      }
       qf[qt][ks] = __builtin_bit_cast(vec8, t);
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[qt][ks][j] = (elem)((float)qf[qt][ks][j] * c2);
@@ -122,6 +151,33 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
     }
   };
 
+  // ---- KV8 staging: tile t = BN x D bytes per operand = NL loads of 16 e4m3 per lane; load i covers row (64 i + lane) 16 / D, bf16
+  // chunks 2 ((lane 16 / 8) % CPR') .. +1 -- written into the images above with their swizzles
+  constexpr int NL = KV8 ? D / 16 : 1;
+  u32x4 kraw[NL], vraw[NL];
+  auto load_raw = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const unsigned off = (unsigned)t * (BN * D) + (unsigned)(i * 64 + lane) * 16;
+      kraw[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0);
+      vraw[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0);
+    }
+  };
+  auto write_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int e0 = (i * 64 + lane) * 16, row = e0 / D, ch = (e0 % D) / 8;  // ch even: chunks ch, ch + 1
+      const int ksw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+      const int vsw = (D == 64) ? (((row >> 1) & 3) << 1) : ((row & 7) << 1);
+      const unsigned k0 = kraw[i][0], k1 = kraw[i][1], k2 = kraw[i][2], k3 = kraw[i][3];
+      const unsigned v0 = vraw[i][0], v1 = vraw[i][1], v2 = vraw[i][2], v3 = vraw[i][3];
+      lds_write_b128(Kbuf + buf * TILE + row * RB + ((ch ^ ksw) << 4), widen8(k0, k1));
+      lds_write_b128(Kbuf + buf * TILE + row * RB + (((ch + 1) ^ ksw) << 4), widen8(k2, k3));
+      lds_write_b128(Vbuf + buf * TILE + row * RB + ((ch ^ vsw) << 4), widen8(v0, v1));
+      lds_write_b128(Vbuf + buf * TILE + row * RB + (((ch + 1) ^ vsw) << 4), widen8(v2, v3));
+    }
+  };
+
   f32x4 oacc[DT][QT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt)
@@ -137,11 +193,22 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
   }
 
   if (t0 < t1) {
-    stage_dma(t0, 0);
+    if constexpr (KV8) {
+      load_raw(t0);
+      write_tile(0);
+    } else {
+      stage_dma(t0, 0);
+    }
     for (int t = t0; t < t1; ++t) {
-      const int buf = (t - t0) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t has landed (this wave issued every piece of it: no barrier needed)
-      if (t + 1 < t1) stage_dma(t + 1, buf ^ 1);         // the next tile streams under this tile's arithmetic
+      // (KV8: ONE LDS image -- the next tile waits in registers and overwrites it behind this tile's arithmetic -- so an item holds half
+      // the LDS and twice as many items, i.e. loads, are in flight per CU: the path is bound by tiles in flight, not by bytes)
+      const int buf = KV8 ? 0 : ((t - t0) & 1);
+      if constexpr (KV8) {
+        if (t + 1 < t1) load_raw(t + 1);  // the next tile's loads fly under this tile's arithmetic; widened and written behind it
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t has landed (this wave issued every piece of it: no barrier needed)
+        if (t + 1 < t1) stage_dma(t + 1, buf ^ 1);         // the next tile streams under this tile's arithmetic
+      }
       const int kv0 = t * BN;
       const unsigned bo = (unsigned)(buf * TILE);
       // ---- S^T = K.Q~^T (log2 units): s[kt][qt][i] = S[row 16qt + c][key kv0 + 16kt + 4g + i]
@@ -214,6 +281,9 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = M::mfma(__builtin_bit_cast(vec8, v8), pf[kp][qt], oacc[dt][qt]);
         }
+      if constexpr (KV8) {
+        if (t + 1 < t1) write_tile(0);  // (one wave, LDS operations in order: this tile's reads are behind us)
+      }
     }
   }
 
@@ -301,7 +371,9 @@ __global__ __launch_bounds__(64) void decode_combine_kernel(DecodeParams p) {
 }
 
 // ---------------------------------------------------------------------------
-bool decode_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16) && (D == 64 || D == 128); }
+bool decode_supported(int dtype, int D) {
+  return (dtype == FA_DTYPE_F16 || dtype == FA_DTYPE_BF16 || dtype == FA_DTYPE_FP8_E4M3) && (D == 64 || D == 128);
+}
 
 // splits per (batch, key head): one round of the chip's item slots (an item keeps one tile in flight: 4-5 / 2 items of 16 / 32 KiB per
 // CU are what fills the memory pipe), but at least FA_DECODE_MIN_TILES 64-key tiles per item so that its prologue amortises
@@ -311,9 +383,9 @@ bool decode_supported(int dtype, int D) { return (dtype == FA_DTYPE_F16 || dtype
 #ifndef FA_DECODE_ROUNDS
 #define FA_DECODE_ROUNDS 1
 #endif
-int decode_splits(int B, int Hkv, int Nk, int D) {
+int decode_splits(int B, int Hkv, int Nk, int D, int kv8) {
   const int nT = (Nk + BN - 1) / BN;
-  const int per_cu = (D == 64) ? 5 : 2;  // items resident per CU (32 / 64 KiB of LDS each)
+  const int per_cu = ((D == 64) ? 5 : 2) * (kv8 ? 2 : 1);  // items resident per CU (32 / 64 KiB of LDS each; e4m3 inputs: one image, half)
   const long long want = (long long)FA_DECODE_ROUNDS * 256 * per_cu;
   long long S = (want + (long long)B * Hkv - 1) / ((long long)B * Hkv);
   S = std::min<long long>(S, std::max(1, nT / FA_DECODE_MIN_TILES));
@@ -322,19 +394,20 @@ int decode_splits(int B, int Hkv, int Nk, int D) {
 
 long long decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, int D) {
   const int R = (Hq / Hkv) * Nq, QT = (R + 15) / 16;
-  return (long long)B * Hkv * decode_splits(B, Hkv, Nk, D) * (16 * QT) * (D + 2) * 4;
+  // (sized for the larger of the two split counts -- e4m3 inputs run twice the items -- so that one workspace serves every dtype)
+  return (long long)B * Hkv * std::max(decode_splits(B, Hkv, Nk, D, 0), decode_splits(B, Hkv, Nk, D, 1)) * (16 * QT) * (D + 2) * 4;
 }
 
-template <typename Tag, int D, int QT>
+template <typename Tag, int D, int QT, bool KV8 = false>
 static hipError_t launch_decode_q(const DecodeParams &p, hipStream_t s) {
-  const size_t smem = 4 * (size_t)BN * D * 2;
+  const size_t smem = (KV8 ? 2 : 4) * (size_t)BN * D * 2;
   (void)hipGetLastError();
   if (p.is_causal) {
-    auto kern = decode_partial_kernel<Tag, D, QT, true>;
+    auto kern = decode_partial_kernel<Tag, D, QT, true, KV8>;
     if (smem > 48 * 1024) { hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, dim3(p.B * p.Hkv * p.S), dim3(64), smem, s, p);
   } else {
-    auto kern = decode_partial_kernel<Tag, D, QT, false>;
+    auto kern = decode_partial_kernel<Tag, D, QT, false, KV8>;
     if (smem > 48 * 1024) { hipError_t e = set_dyn_lds_once((const void *)kern, (int)smem); if (e != hipSuccess) return e; }
     hipLaunchKernelGGL(kern, dim3(p.B * p.Hkv * p.S), dim3(64), smem, s, p);
   }
@@ -352,6 +425,11 @@ hipError_t launch_decode(const DecodeParams &p, int D, int dtype, hipStream_t s)
     if (D == 128) return QT == 1 ? launch_decode_q<Tag, 128, 1>(p, s) : launch_decode_q<Tag, 128, 2>(p, s);
     return hipErrorInvalidValue;
   };
+  if (dtype == FA_DTYPE_FP8_E4M3) {  // e4m3 Q, K, V; bf16 arithmetic and output
+    if (D == 64) return QT == 1 ? launch_decode_q<BF16, 64, 1, true>(p, s) : launch_decode_q<BF16, 64, 2, true>(p, s);
+    if (D == 128) return QT == 1 ? launch_decode_q<BF16, 128, 1, true>(p, s) : launch_decode_q<BF16, 128, 2, true>(p, s);
+    return hipErrorInvalidValue;
+  }
   return dtype == FA_DTYPE_F16 ? go(F16{}) : go(BF16{});
 }
 

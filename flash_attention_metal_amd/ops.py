@@ -211,15 +211,17 @@ def flash_attention_decode(
         raise ValueError(f"incompatible shapes q {tuple(q.shape)} k/v {tuple(k.shape)}")
     if not (q.is_cuda and k.is_cuda and v.is_cuda):
         raise RuntimeError("flash_attention_decode needs device tensors: there is no CPU path")
-    if q.dtype not in (torch.float16, torch.bfloat16) or k.dtype != q.dtype or v.dtype != q.dtype:
+    fp8 = getattr(torch, "float8_e4m3fn", None)
+    if q.dtype not in (torch.float16, torch.bfloat16, fp8) or k.dtype != q.dtype or v.dtype != q.dtype:
         raise ValueError(f"unsupported / mixed dtypes {q.dtype} {k.dtype} {v.dtype}")
+    odt = torch.bfloat16 if q.dtype == fp8 else q.dtype  # e4m3 inputs (an e4m3 KV cache): bf16 output, as in flash_attention_forward
     qbs, qhs = _strides(q)
     kbs, khs = _strides(k)
     if _strides(v) != (kbs, khs):
         raise ValueError("k and v must share batch/head strides")
     if out is None:
-        out = torch.empty_strided((B, Hq, Nq, D), q.stride(), dtype=q.dtype, device=q.device)
-    elif not out.is_cuda or out.device != q.device or out.dtype != q.dtype or out.shape != q.shape or _strides(out) != (qbs, qhs):
+        out = torch.empty_strided((B, Hq, Nq, D), q.stride(), dtype=odt, device=q.device)
+    elif not out.is_cuda or out.device != q.device or out.dtype != odt or out.shape != q.shape or _strides(out) != (qbs, qhs):
         raise ValueError("out must be a device tensor with q's shape/strides")
     if return_lse and lse is None:
         lse = torch.empty((B, Hq, Nq), dtype=torch.float32, device=q.device)

@@ -166,11 +166,14 @@ int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
 
 /*
  * Few query rows against a long key sequence (decode steps, short chunks; scope row f3, not in the reference): the same operator as
- * fa_fwd_ex for (Hq / Hkv) * Nq <= 32, f16 / bf16, D = 64 | 128, laid out for the HBM roofline instead of the matrix cores -- the query
+ * fa_fwd_ex for (Hq / Hkv) * Nq <= 32, f16 / bf16 / e4m3, D = 64 | 128, laid out for the HBM roofline instead of the matrix cores -- the query
  * heads of a key/value head are packed into one row block (K and V are read once per key head), the keys are split over several
  * work items per (batch, key head), and the partial results (unnormalised O, m, l per item) meet in `workspace`, caller-owned device
  * memory of fa_fwd_decode_workspace_bytes() bytes, 16-byte aligned, contents irrelevant before and after the call; a second launch
  * on the same stream combines them. Pre-scaled query operand as FA_VARIANT_MFMA ("LSE accuracy" above). Asynchronous, allocates nothing.
+ * dtype FA_DTYPE_FP8_E4M3 (an e4m3 KV cache: Q, K, V e4m3 under strides that are multiples of 16, O bf16 as in fa_fwd): half the bytes of
+ * the stream; the tiles are widened EXACTLY to bf16 on their way into LDS, so the arithmetic and the tolerances are the bf16 path's (the
+ * probabilities stay bf16 here). The workspace size does not depend on the dtype.
  */
 int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *lse,
                   int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,

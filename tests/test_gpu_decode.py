@@ -60,6 +60,37 @@ def test_decode_vs_oracle_and_fwd_ex(fa, oracle_mod, dtype):
             assert np.abs(on[:, :, :1] - o1).max() < TOL_O[dtype], what
 
 
+def test_decode_e4m3_inputs(fa, oracle_mod):
+    """An e4m3 KV cache (and e4m3 queries: dtype fp8_e4m3, the forward's config-5 family; bf16 output): the tiles are widened exactly to
+    bf16 on their way into LDS, so the arithmetic per tile is that of the bf16 decode on the widened tensors -- and the result holds the
+    bf16 bar against the fp64 oracle on the e4m3 values."""
+    import torch
+
+    rng = np.random.default_rng(22)
+    for (B, Hq, Hkv, Nq, Nk, D, causal) in CASES:
+        if Nk * D % 16:  # e4m3 heads are 16-byte aligned
+            continue
+        q = oracle_mod.round_to(2.0 * oracle_mod.init_random(B * Hq * Nq * D, int(rng.integers(1, 1 << 20))).reshape(B, Hq, Nq, D), "fp8")
+        k = oracle_mod.round_to(2.0 * oracle_mod.init_random(B * Hkv * Nk * D, int(rng.integers(1, 1 << 20))).reshape(B, Hkv, Nk, D), "fp8")
+        v = oracle_mod.round_to(2.0 * oracle_mod.init_random(B * Hkv * Nk * D, int(rng.integers(1, 1 << 20))).reshape(B, Hkv, Nk, D), "fp8")
+        what = (B, Hq, Hkv, Nq, Nk, D, causal)
+        o8, l8 = fa.flash_attention_decode(to_dev(q, "fp8"), to_dev(k, "fp8"), to_dev(v, "fp8"), is_causal=causal)
+        ob, lb = fa.flash_attention_decode(to_dev(q, "bf16"), to_dev(k, "bf16"), to_dev(v, "bf16"), is_causal=causal)
+        torch.cuda.synchronize()
+        # (the same arithmetic per tile as the bf16 path on the widened tensors; the e4m3 path splits the keys over twice the items,
+        # so the partial results combine in another order: close, not equal)
+        assert o8.dtype == torch.bfloat16 and (o8.float() - ob.float()).abs().max().item() < TOL_O["bf16"], what
+        assert (l8 - lb).abs().max().item() < 2e-5, what
+        o64, l64 = oracle_mod.attn_fwd_ex_f64(q, k, v, causal)
+        assert np.abs(o8.float().cpu().numpy() - o64).max() < 2 * TOL_O["bf16"], what
+        assert np.abs(l8.cpu().numpy() - l64).max() < lse_tol("bf16", 1, q, k), what
+    # dtypes must agree; strides of an e4m3 tensor are multiples of 16
+    x = torch.zeros(1, 8, 1, 64, dtype=torch.float8_e4m3fn, device="cuda")
+    kv = torch.zeros(1, 8, 200, 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        fa.flash_attention_decode(x, kv, kv)
+
+
 def test_decode_known_answers_and_workspace(fa, oracle_mod):
     import torch
 

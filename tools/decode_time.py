@@ -38,4 +38,14 @@ for (B, Hq, Hkv, Nq, Nk, D) in shapes:
         e1.record(); torch.cuda.synchronize()
         us2 = e0.elapsed_time(e1) / 50 * 1e3
         line += f" | fa_fwd_decode {us2:8.1f} us {byts / us2 / 1e6:.2f} TB/s ({us / us2:.1f}x)"
+        # the same step on an e4m3 KV cache (dtype 3: Q, K, V e4m3, bf16 output): half the bytes
+        q8, k8, v8 = (x.to(torch.float8_e4m3fn) for x in (q, k, v))
+        a8 = (q8.data_ptr(), k8.data_ptr(), v8.data_ptr()) + args[3:17] + (3,) + args[18:]
+        for _ in range(5): assert lib.fa_fwd_decode(*a8) == 0
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(50): lib.fa_fwd_decode(*a8)
+        e1.record(); torch.cuda.synchronize()
+        us3 = e0.elapsed_time(e1) / 50 * 1e3
+        line += f" | e4m3 {us3:8.1f} us {byts / 2 / us3 / 1e6:.2f} TB/s ({us2 / us3:.2f}x)"
     print(line + f"   K+V {byts / 1e6:7.1f} MB", flush=True)
