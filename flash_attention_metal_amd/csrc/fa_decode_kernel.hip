@@ -24,6 +24,10 @@
 
 #include "fa_mfma_common.h"
 
+#ifndef FA_DECODE_KV8_DEPTH
+#define FA_DECODE_KV8_DEPTH 1  // e4m3 inputs, head_dim 64: tiles waiting in registers (1; 2 measured 0-13 % slower: 160 instead of 128 registers, profiles/r04/decode_ab_kv8_depth.log)
+#endif
+
 namespace fa {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -154,23 +158,28 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
   // ---- KV8 staging: tile t = BN x D bytes per operand = NL loads of 16 e4m3 per lane; load i covers row (64 i + lane) 16 / D, bf16
   // chunks 2 ((lane 16 / 8) % CPR') .. +1 -- written into the images above with their swizzles
   constexpr int NL = KV8 ? D / 16 : 1;
-  u32x4 kraw[NL], vraw[NL];
-  auto load_raw = [&](int t) {
+  // DEPTH tiles wait in registers (one; the knob allows two at head_dim 64)
+  constexpr int DEPTH = (KV8 && D == 64) ? FA_DECODE_KV8_DEPTH : 1;
+  u32x4 kraw[DEPTH][NL], vraw[DEPTH][NL];
+  auto load_raw = [&](int t, auto slotc) {
+    constexpr int slot = decltype(slotc)::value;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const unsigned off = (unsigned)t * (BN * D) + (unsigned)(i * 64 + lane) * 16;
-      kraw[i] = __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0);
-      vraw[i] = __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0);
+      kraw[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0);
+      vraw[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0);
     }
   };
-  auto write_tile = [&](int buf) {
+  auto write_tile = [&](auto slotc) {  // registers of slot -> the (one) LDS image
+    constexpr int slot = decltype(slotc)::value;
+    constexpr int buf = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int e0 = (i * 64 + lane) * 16, row = e0 / D, ch = (e0 % D) / 8;  // ch even: chunks ch, ch + 1
       const int ksw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
       const int vsw = (D == 64) ? (((row >> 1) & 3) << 1) : ((row & 7) << 1);
-      const unsigned k0 = kraw[i][0], k1 = kraw[i][1], k2 = kraw[i][2], k3 = kraw[i][3];
-      const unsigned v0 = vraw[i][0], v1 = vraw[i][1], v2 = vraw[i][2], v3 = vraw[i][3];
+      const unsigned k0 = kraw[slot][i][0], k1 = kraw[slot][i][1], k2 = kraw[slot][i][2], k3 = kraw[slot][i][3];
+      const unsigned v0 = vraw[slot][i][0], v1 = vraw[slot][i][1], v2 = vraw[slot][i][2], v3 = vraw[slot][i][3];
       lds_write_b128(Kbuf + buf * TILE + row * RB + ((ch ^ ksw) << 4), widen8(k0, k1));
       lds_write_b128(Kbuf + buf * TILE + row * RB + (((ch + 1) ^ ksw) << 4), widen8(k2, k3));
       lds_write_b128(Vbuf + buf * TILE + row * RB + ((ch ^ vsw) << 4), widen8(v0, v1));
@@ -192,19 +201,14 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
     l[qt] = 0.0f;
   }
 
-  if (t0 < t1) {
-    if constexpr (KV8) {
-      load_raw(t0);
-      write_tile(0);
-    } else {
-      stage_dma(t0, 0);
-    }
-    for (int t = t0; t < t1; ++t) {
+  // one tile: (KV8) the tile is in the LDS image, register slot `slot` -- which held it -- is free for tile t + DEPTH; slot + 1 holds tile t + 1
+  auto step = [&](auto slotc, const int t) {
+      constexpr int slot = decltype(slotc)::value;
       // (KV8: ONE LDS image -- the next tile waits in registers and overwrites it behind this tile's arithmetic -- so an item holds half
       // the LDS and twice as many items, i.e. loads, are in flight per CU: the path is bound by tiles in flight, not by bytes)
       const int buf = KV8 ? 0 : ((t - t0) & 1);
       if constexpr (KV8) {
-        if (t + 1 < t1) load_raw(t + 1);  // the next tile's loads fly under this tile's arithmetic; widened and written behind it
+        if (t + DEPTH < t1) load_raw(t + DEPTH, slotc);  // flies under this and the next tile's arithmetic; widened and written behind it
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t has landed (this wave issued every piece of it: no barrier needed)
         if (t + 1 < t1) stage_dma(t + 1, buf ^ 1);         // the next tile streams under this tile's arithmetic
@@ -282,7 +286,23 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
           for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = M::mfma(__builtin_bit_cast(vec8, v8), pf[kp][qt], oacc[dt][qt]);
         }
       if constexpr (KV8) {
-        if (t + 1 < t1) write_tile(0);  // (one wave, LDS operations in order: this tile's reads are behind us)
+        if (t + 1 < t1) write_tile(std::integral_constant<int, (slot + 1) % DEPTH>{});  // (one wave, LDS operations in order: this tile's reads are behind us)
+      }
+  };
+  if (t0 < t1) {
+    if constexpr (KV8) {
+      load_raw(t0, std::integral_constant<int, 0>{});
+      if constexpr (DEPTH == 2) {
+        if (t0 + 1 < t1) load_raw(t0 + 1, std::integral_constant<int, 1>{});
+      }
+      write_tile(std::integral_constant<int, 0>{});
+    } else {
+      stage_dma(t0, 0);
+    }
+    for (int t = t0; t < t1; t += DEPTH) {
+      step(std::integral_constant<int, 0>{}, t);
+      if constexpr (DEPTH == 2) {
+        if (t + 1 < t1) step(std::integral_constant<int, 1>{}, t + 1);
       }
     }
   }

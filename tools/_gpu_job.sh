@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
-tail -3 gpurun_out/gpu_tests_full.log
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 || { tail -20 gpurun_out/smoke.log; exit 1; }
-tail -3 gpurun_out/smoke.log
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+DECODE_AB_FP8=1 timeout -k 10 600 python tools/decode_ab.py tools/ab/lib_kvd1.so $L > gpurun_out/decode_ab_kv8_depth.log 2>&1
+cat gpurun_out/decode_ab_kv8_depth.log
+timeout -k 10 600 python -m pytest tests/test_gpu_decode.py -x -q 2>&1 | tail -2

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""fa_fwd_decode of several builds, interleaved in one process (raw C-ABI calls). usage: decode_ab.py lib1.so lib2.so ... """
+"""fa_fwd_decode of several builds, interleaved in one process (raw C-ABI calls). usage: [DECODE_AB_FP8=1] decode_ab.py lib1.so lib2.so ...
+(DECODE_AB_FP8=1: e4m3 Q / K / V, dtype 3)"""
 import ctypes, os, sys
 from ctypes import c_int, c_float, c_longlong, c_void_p
 import torch
@@ -15,15 +16,17 @@ shapes = [(1, 32, 8, 1, 4096, 64), (1, 32, 8, 1, 16384, 64), (1, 32, 32, 1, 1638
 for (B, Hq, Hkv, Nq, Nk, D) in shapes:
     q = torch.randn(B, Hq, Nq, D, device="cuda", dtype=torch.bfloat16); k = torch.randn(B, Hkv, Nk, D, device="cuda", dtype=torch.bfloat16); v = torch.randn_like(k)
     o = torch.empty_like(q); lse = torch.empty(B, Hq, Nq, dtype=torch.float32, device="cuda")
+    FP8 = bool(os.environ.get("DECODE_AB_FP8"))
+    if FP8: q, k, v = (x.to(torch.float8_e4m3fn) for x in (q, k, v))
     st = torch.cuda.current_stream().cuda_stream
-    byts = 2 * B * Hkv * Nk * D * 2
+    byts = 2 * B * Hkv * Nk * D * (1 if FP8 else 2)
     line = f"B{B} Hq{Hq} Hkv{Hkv} Nq{Nq} Nk{Nk} D{D} ({byts/1e6:.0f} MB):"
     res = [[] for _ in libs]
     wss = [torch.empty(max(16, l.fa_fwd_decode_workspace_bytes(B, Hq, Hkv, Nq, Nk, D)), dtype=torch.uint8, device="cuda") for l in libs]
     for rnd in range(6):
         for i, l in enumerate(libs):
             args = (q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B, Hq, Hkv, Nq, Nk, D, D ** -0.5, Hq * Nq * D, Nq * D,
-                    Hkv * Nk * D, Nk * D, 1, 2, wss[i].data_ptr(), wss[i].numel(), st)
+                    Hkv * Nk * D, Nk * D, 1, 3 if FP8 else 2, wss[i].data_ptr(), wss[i].numel(), st)
             for _ in range(3): assert l.fa_fwd_decode(*args) == 0
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
