@@ -1,7 +1,6 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 600 python -m pytest tests/test_gpu_decode.py -x -q > gpurun_out/decode_tests.log 2>&1 || { tail -30 gpurun_out/decode_tests.log; exit 1; }
-tail -2 gpurun_out/decode_tests.log
-timeout -k 10 600 python tools/decode_time.py > gpurun_out/decode_time_final2.log 2>&1
-tail -12 gpurun_out/decode_time_final2.log
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+timeout -k 10 900 python tools/ab_bwd.py $L tools/ab/lib_bwd_la2.so tools/ab/lib_bwd_la4.so tools/ab/lib_bwd_lb1.so tools/ab/lib_bwd_lb3.so --shapes c3,nc4k --rounds 8 --iters 4 > gpurun_out/ab_bwd_knobs_warm.log 2>&1
+cat gpurun_out/ab_bwd_knobs_warm.log

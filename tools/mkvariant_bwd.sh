@@ -9,7 +9,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/flash_attention_metal_amd/csrc
 out=$root/tools/ab
 mkdir -p $out/obj_$name
-for f in fa_api fa_scalar_kernels fa_mfma_kernel fa_fwd_pp_kernel fa_fwd_splitkv_kernel; do cp $src/$f.o $out/obj_$name/$f.o; done
+for f in $src/*.o; do b=$(basename $f .o); [ "$b" = fa_bwd_kernels ] || cp $f $out/obj_$name/$b.o; done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -fno-honor-nans -fno-slp-vectorize $extra \
   -c $src/fa_bwd_kernels.hip -o $out/obj_$name/fa_bwd_kernels.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/lib_$name.so $out/obj_$name/*.o
