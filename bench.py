@@ -306,6 +306,8 @@ def main() -> int:
         }
         if c4 is not None:
             out["c4_slice"] = c4
+        if world == 1 and not args.no_c4:
+            out["c5_fp8"] = c5_fp8(fa, torch, dev)
         if world == 1 and not args.no_sweep:
             out["sweep"] = sweep(fa, torch, dev)
             at = [r for r in out["sweep"] if r["seqlen"] == N]
@@ -343,6 +345,31 @@ def c4_slice(fa, torch, ranks, info, dev, iters=10):
                         f"head_dim={C4_D}, bf16, causal",
             "tflops_total": round(per_s / 1e12, 2), "ms_per_step": round(worst / iters * 1e3, 4),
             "mfma_frac": round(per_s / 1e12 / (PEAK_TFLOPS_BF16 * info.world), 4), "steps": iters}
+
+
+def c5_fp8(fa, torch, dev, iters=10):
+    """BASELINE configs[4]: seqlen 8192, head_dim 64, e4m3 Q/K/V with fp32 accumulate (bf16 O), causal, B=4 x H=16 as config 3 (the
+    batch is not stated there). Informational block of the N=1 line: AUTO's kernel, HIP events around the launches."""
+    g = torch.Generator(device=dev).manual_seed(8000)
+    mk = lambda: (torch.rand(B_PER_GPU, H, 8192, D, generator=g, device=dev) * 2 - 1).to(torch.float8_e4m3fn)  # noqa: E731
+    q, k, v = mk(), mk(), mk()
+    step = fa.ForwardPlan(q, k, v, is_causal=True).launch
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.1:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        step()
+    b.record()
+    torch.cuda.synchronize(dev)
+    ms = a.elapsed_time(b) / iters
+    tf = fa.algorithmic_flops(B_PER_GPU, H, 8192, D, True) / (ms * 1e-3) / 1e12
+    return {"workload": f"BASELINE.json configs[4]: seqlen=8192 head_dim={D} batch={B_PER_GPU} heads={H} fp8_e4m3 in / fp32 accumulate / bf16 out, causal",
+            "tflops": round(tf, 2), "ms_per_step": round(ms, 4), "kernel": fa.forward_kernel_name("fp8_e4m3", D, True, B_PER_GPU, H, 8192),
+            "frac_of_bf16_mfma_peak": round(tf / PEAK_TFLOPS_BF16, 4), "steps": iters}
 
 
 def rehearsal(args, ranks) -> int:

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-L=flash_attention_metal_amd/csrc/libfa_mi355.so
-timeout -k 10 900 python tools/ab_bwd.py $L tools/ab/lib_bwd_la2.so tools/ab/lib_bwd_la4.so tools/ab/lib_bwd_lb1.so tools/ab/lib_bwd_lb3.so --shapes c3,nc4k --rounds 8 --iters 4 > gpurun_out/ab_bwd_knobs_warm.log 2>&1
-cat gpurun_out/ab_bwd_knobs_warm.log
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err || { tail -20 gpurun_out/bench_c5.err; exit 1; }
+python3 -c "
+import json; r=json.loads(open('gpurun_out/bench_c5.json').read().strip().splitlines()[-1]); print(r['value'], r['roofline']['kernel'], r['c5_fp8'], r['c4_slice']['tflops_total'])"
