@@ -1,6 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err || { tail -20 gpurun_out/bench_c5.err; exit 1; }
-python3 -c "
-import json; r=json.loads(open('gpurun_out/bench_c5.json').read().strip().splitlines()[-1]); print(r['value'], r['roofline']['kernel'], r['c5_fp8'], r['c4_slice']['tflops_total'])"
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+timeout -k 10 600 python tools/ab.py tools/ab/lib_fp8_mov.so:11 $L:11 --shapes c5,c5d128,c5 --rounds 8 --iters 10 --warm-ms 500 > gpurun_out/ab_fp8_nomov.log 2>&1
+cat gpurun_out/ab_fp8_nomov.log
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "fp8" 2>&1 | tail -2
