@@ -1,7 +1,7 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-L=flash_attention_metal_amd/csrc/libfa_mi355.so
-timeout -k 10 600 python tools/ab.py tools/ab/lib_fp8_mov.so:11 $L:11 --shapes c5,c5d128,c5 --rounds 8 --iters 10 --warm-ms 500 > gpurun_out/ab_fp8_nomov.log 2>&1
-cat gpurun_out/ab_fp8_nomov.log
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "fp8" 2>&1 | tail -2
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
+tail -2 gpurun_out/gpu_tests_full.log
+timeout -k 10 1500 bash tools/collect_profiles.sh r04g > gpurun_out/collect_r04g.log 2>&1 || { tail -30 gpurun_out/collect_r04g.log; exit 1; }
+grep -E "^c[2-5]|bwd B4|PASSED|FAILED" gpurun_out/collect_r04g.log | tail -24
