@@ -1,7 +1,6 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
-tail -2 gpurun_out/gpu_tests_full.log
-timeout -k 10 1500 bash tools/collect_profiles.sh r04g > gpurun_out/collect_r04g.log 2>&1 || { tail -30 gpurun_out/collect_r04g.log; exit 1; }
-grep -E "^c[2-5]|bwd B4|PASSED|FAILED" gpurun_out/collect_r04g.log | tail -24
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+timeout -k 10 900 python tools/ab.py $L:10 tools/ab/lib_sumv.so:10 --shapes c3,c16k,nc4k,c4 --rounds 8 --iters 10 --warm-ms 600 > gpurun_out/ab_sumv.log 2>&1
+cat gpurun_out/ab_sumv.log
