@@ -393,7 +393,7 @@ static int bwd_impl(const char *fn, const void *q, const void *k, const void *v,
     return fail(FA_ERR_UNSUPPORTED, "%s: no kernel for dtype=%s D=%d (f16 / bf16 / fp8_e4m3, D a multiple of 8 up to 128)", fn, fa_dtype_name(dtype), D);
   if ((double)(N > Nk ? N : Nk) * D * 2 >= 4294967296.0) return fail(FA_ERR_INVALID_ARG, "%s: one head exceeds 4 GiB", fn);
   // head dims other than 64 / 128 run on zero-padded rows whose padding is fetched from offset 2^31 + ... (fa_bwd_kernels.hip, PAD)
-  if (D != 64 && D != 128 && (double)(N > Nk ? N : Nk) * D * 2 >= 2147483648.0)
+  if (D != 64 && D != 128 && D != 256 && (double)((N > Nk ? N : Nk) + 128) * D * 2 >= 2147483648.0)  // (+128: rows past the end are addressed too)
     return fail(FA_ERR_INVALID_ARG, "%s: one head exceeds 2 GiB (head dims other than 64 / 128)", fn);
   if (bs < 0 || kbs < 0) return fail(FA_ERR_INVALID_ARG, "%s: negative batch stride", fn);
   if ((long long)B * H > 0x7fffffffLL / (((N > Nk ? N : Nk) + 127) / 128)) return fail(FA_ERR_INVALID_ARG, "%s: grid too large", fn);
