@@ -289,7 +289,10 @@ int fa_fwd_exv(const void *q, const void *k, const void *v, void *o, float *lse,
     // the 16x16x32 kernel where fa_fwd's AUTO takes it: head_dim 64, 16-bit inputs, long key sequences on a grid that fills the chip
     variant = small_grid ? FA_VARIANT_MFMA_SPLITKV
               : padded_dim ? FA_VARIANT_MFMA16
-              : (fa::mfma16_supported(dtype, D) && Nk >= (D == 64 ? 2048 : 8192) && blocks128 > 512) ? FA_VARIANT_MFMA16 : FA_VARIANT_MFMA;
+              : (fa::mfma16_supported(dtype, D) && blocks128 > 512 &&
+                 Nk >= (D == 64 ? (is_causal ? 1536 : 1024) : (is_causal ? 2048 : 1024)))  // (fa_fwd's thresholds, fa_resolve_variant_for)
+                    ? FA_VARIANT_MFMA16
+                    : FA_VARIANT_MFMA;
   }
   // the kernels that take the generalised problem (key/value heads, Nk): the 128-row kernel with / without its pre-scaled operand, its
   // 16x16x32 form, the split-KV kernel
