@@ -24,6 +24,9 @@
 
 #include "fa_mfma_common.h"
 
+#ifndef FA_DECODE_REGSTAGE
+#define FA_DECODE_REGSTAGE 0  // 1 (experiment): 16-bit inputs also travel through registers into ONE LDS image (twice the items per CU), as e4m3 inputs do
+#endif
 #ifndef FA_DECODE_KV8_DEPTH
 #define FA_DECODE_KV8_DEPTH 1  // e4m3 inputs, head_dim 64: tiles waiting in registers (1; 2 measured 0-13 % slower: 160 instead of 128 registers, profiles/r04/decode_ab_kv8_depth.log)
 #endif
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
 
   extern __shared__ __attribute__((aligned(16))) char smem_generic[];
   lds_char *smem = (lds_char *)smem_generic;
-  lds_char *Kbuf = smem, *Vbuf = smem + (KV8 ? 1 : 2) * TILE;
+  constexpr bool RS = KV8 || (FA_DECODE_REGSTAGE != 0);  // tiles staged through registers into one LDS image
+  lds_char *Kbuf = smem, *Vbuf = smem + (RS ? 1 : 2) * TILE;
 
   const int lane = threadIdx.x;
   const int c = lane & 15, g = lane >> 4;
@@ -157,15 +161,16 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
 
   // ---- KV8 staging: tile t = BN x D bytes per operand = NL loads of 16 e4m3 per lane; load i covers row (64 i + lane) 16 / D, bf16
   // chunks 2 ((lane 16 / 8) % CPR') .. +1 -- written into the images above with their swizzles
-  constexpr int NL = KV8 ? D / 16 : 1;
+  constexpr int NL = RS ? D * EB / 16 : 1;
   // DEPTH tiles wait in registers (one; the knob allows two at head_dim 64)
   constexpr int DEPTH = (KV8 && D == 64) ? FA_DECODE_KV8_DEPTH : 1;
+  static_assert(EB == 1 || EB == 2, "");
   u32x4 kraw[DEPTH][NL], vraw[DEPTH][NL];
   auto load_raw = [&](int t, auto slotc) {
     constexpr int slot = decltype(slotc)::value;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const unsigned off = (unsigned)t * (BN * D) + (unsigned)(i * 64 + lane) * 16;
+      const unsigned off = (unsigned)t * (BN * D * EB) + (unsigned)(i * 64 + lane) * 16;
       kraw[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rk, off, 0, 0);
       vraw[slot][i] = __builtin_amdgcn_raw_buffer_load_b128(rv, off, 0, 0);
     }
@@ -175,15 +180,20 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
     constexpr int buf = 0;
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
-      const int e0 = (i * 64 + lane) * 16, row = e0 / D, ch = (e0 % D) / 8;  // ch even: chunks ch, ch + 1
+      const int e0 = (i * 64 + lane) * (16 / EB), row = e0 / D, ch = (e0 % D) / 8;  // (e4m3: ch even, chunks ch and ch + 1)
       const int ksw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
       const int vsw = (D == 64) ? (((row >> 1) & 3) << 1) : ((row & 7) << 1);
-      const unsigned k0 = kraw[slot][i][0], k1 = kraw[slot][i][1], k2 = kraw[slot][i][2], k3 = kraw[slot][i][3];
-      const unsigned v0 = vraw[slot][i][0], v1 = vraw[slot][i][1], v2 = vraw[slot][i][2], v3 = vraw[slot][i][3];
-      lds_write_b128(Kbuf + buf * TILE + row * RB + ((ch ^ ksw) << 4), widen8(k0, k1));
-      lds_write_b128(Kbuf + buf * TILE + row * RB + (((ch + 1) ^ ksw) << 4), widen8(k2, k3));
-      lds_write_b128(Vbuf + buf * TILE + row * RB + ((ch ^ vsw) << 4), widen8(v0, v1));
-      lds_write_b128(Vbuf + buf * TILE + row * RB + (((ch + 1) ^ vsw) << 4), widen8(v2, v3));
+      if constexpr (KV8) {
+        const unsigned k0 = kraw[slot][i][0], k1 = kraw[slot][i][1], k2 = kraw[slot][i][2], k3 = kraw[slot][i][3];
+        const unsigned v0 = vraw[slot][i][0], v1 = vraw[slot][i][1], v2 = vraw[slot][i][2], v3 = vraw[slot][i][3];
+        lds_write_b128(Kbuf + buf * TILE + row * RB + ((ch ^ ksw) << 4), widen8(k0, k1));
+        lds_write_b128(Kbuf + buf * TILE + row * RB + (((ch + 1) ^ ksw) << 4), widen8(k2, k3));
+        lds_write_b128(Vbuf + buf * TILE + row * RB + ((ch ^ vsw) << 4), widen8(v0, v1));
+        lds_write_b128(Vbuf + buf * TILE + row * RB + (((ch + 1) ^ vsw) << 4), widen8(v2, v3));
+      } else {
+        lds_write_b128(Kbuf + buf * TILE + row * RB + ((ch ^ ksw) << 4), kraw[slot][i]);
+        lds_write_b128(Vbuf + buf * TILE + row * RB + ((ch ^ vsw) << 4), vraw[slot][i]);
+      }
     }
   };
 
@@ -206,8 +216,8 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
       constexpr int slot = decltype(slotc)::value;
       // (KV8: ONE LDS image -- the next tile waits in registers and overwrites it behind this tile's arithmetic -- so an item holds half
       // the LDS and twice as many items, i.e. loads, are in flight per CU: the path is bound by tiles in flight, not by bytes)
-      const int buf = KV8 ? 0 : ((t - t0) & 1);
-      if constexpr (KV8) {
+      const int buf = RS ? 0 : ((t - t0) & 1);
+      if constexpr (RS) {
         if (t + DEPTH < t1) load_raw(t + DEPTH, slotc);  // flies under this and the next tile's arithmetic; widened and written behind it
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t has landed (this wave issued every piece of it: no barrier needed)
@@ -285,12 +295,12 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = M::mfma(__builtin_bit_cast(vec8, v8), pf[kp][qt], oacc[dt][qt]);
         }
-      if constexpr (KV8) {
+      if constexpr (RS) {
         if (t + 1 < t1) write_tile(std::integral_constant<int, (slot + 1) % DEPTH>{});  // (one wave, LDS operations in order: this tile's reads are behind us)
       }
   };
   if (t0 < t1) {
-    if constexpr (KV8) {
+    if constexpr (RS) {
       load_raw(t0, std::integral_constant<int, 0>{});
       if constexpr (DEPTH == 2) {
         if (t0 + 1 < t1) load_raw(t0 + 1, std::integral_constant<int, 1>{});
@@ -405,7 +415,7 @@ bool decode_supported(int dtype, int D) {
 #endif
 int decode_splits(int B, int Hkv, int Nk, int D, int kv8) {
   const int nT = (Nk + BN - 1) / BN;
-  const int per_cu = ((D == 64) ? 5 : 2) * (kv8 ? 2 : 1);  // items resident per CU (32 / 64 KiB of LDS each; e4m3 inputs: one image, half)
+  const int per_cu = ((D == 64) ? 5 : 2) * ((kv8 || FA_DECODE_REGSTAGE) ? 2 : 1);  // items resident per CU (32 / 64 KiB of LDS each; e4m3 inputs: one image, half)
   const long long want = (long long)FA_DECODE_ROUNDS * 256 * per_cu;
   long long S = (want + (long long)B * Hkv - 1) / ((long long)B * Hkv);
   S = std::min<long long>(S, std::max(1, nT / FA_DECODE_MIN_TILES));
@@ -420,7 +430,7 @@ long long decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, int D) 
 
 template <typename Tag, int D, int QT, bool KV8 = false>
 static hipError_t launch_decode_q(const DecodeParams &p, hipStream_t s) {
-  const size_t smem = (KV8 ? 2 : 4) * (size_t)BN * D * 2;
+  const size_t smem = ((KV8 || FA_DECODE_REGSTAGE) ? 2 : 4) * (size_t)BN * D * 2;
   (void)hipGetLastError();
   if (p.is_causal) {
     auto kern = decode_partial_kernel<Tag, D, QT, true, KV8>;
