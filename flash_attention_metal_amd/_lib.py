@@ -17,6 +17,7 @@ SYMBOLS = {
     "fa_fwd_ex": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_longlong] * 4 + [c_int, c_int, c_void_p]),
     "fa_fwd_exv": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_longlong] * 4 + [c_int, c_int, c_int, c_void_p]),
     "fa_fwd_decode": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_longlong] * 4 + [c_int, c_int, c_void_p, c_longlong, c_void_p]),
+    "fa_fwd_decode_kv8": (c_int, [c_void_p] * 5 + [c_int] * 6 + [c_float] + [c_longlong] * 4 + [c_int, c_int, c_void_p, c_longlong, c_void_p]),
     "fa_fwd_decode_workspace_bytes": (c_longlong, [c_int] * 6),
     "fa_fwd_decode_supported": (c_int, [c_int] * 5),
     "fa_bwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_float, c_longlong, c_longlong, c_int, c_int, c_void_p]),

@@ -317,9 +317,27 @@ long long fa_fwd_decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, 
   if (B < 1 || Hq < 1 || Hkv < 1 || Nq < 1 || Nk < 1 || (D != 64 && D != 128) || Hq % Hkv) return 0;
   return fa::decode_workspace_bytes(B, Hq, Hkv, Nq, Nk, D);
 }
+static int decode_impl(const void *q, const void *k, const void *v, void *o, float *lse, int B, int Hq, int Hkv, int Nq, int Nk, int D,
+                       float scale, long long q_batch_stride, long long q_head_stride, long long kv_batch_stride, long long kv_head_stride,
+                       int is_causal, int dtype, int kv8, void *workspace, long long workspace_bytes, void *hip_stream);
 int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *lse, int B, int Hq, int Hkv, int Nq, int Nk, int D,
                   float scale, long long q_batch_stride, long long q_head_stride, long long kv_batch_stride, long long kv_head_stride,
                   int is_causal, int dtype, void *workspace, long long workspace_bytes, void *hip_stream) {
+  return decode_impl(q, k, v, o, lse, B, Hq, Hkv, Nq, Nk, D, scale, q_batch_stride, q_head_stride, kv_batch_stride, kv_head_stride, is_causal,
+                     dtype, dtype == FA_DTYPE_FP8_E4M3, workspace, workspace_bytes, hip_stream);
+}
+int fa_fwd_decode_kv8(const void *q, const void *k, const void *v, void *o, float *lse, int B, int Hq, int Hkv, int Nq, int Nk, int D,
+                      float scale, long long q_batch_stride, long long q_head_stride, long long kv_batch_stride, long long kv_head_stride,
+                      int is_causal, int q_dtype, void *workspace, long long workspace_bytes, void *hip_stream) {
+  g_err[0] = 0;
+  if (q_dtype != FA_DTYPE_BF16 && q_dtype != FA_DTYPE_FP8_E4M3)
+    return fail(FA_ERR_UNSUPPORTED, "fa_fwd_decode_kv8: queries must be bf16 (or e4m3: then this is fa_fwd_decode), got %s", fa_dtype_name(q_dtype));
+  return decode_impl(q, k, v, o, lse, B, Hq, Hkv, Nq, Nk, D, scale, q_batch_stride, q_head_stride, kv_batch_stride, kv_head_stride, is_causal,
+                     q_dtype, 1, workspace, workspace_bytes, hip_stream);
+}
+static int decode_impl(const void *q, const void *k, const void *v, void *o, float *lse, int B, int Hq, int Hkv, int Nq, int Nk, int D,
+                       float scale, long long q_batch_stride, long long q_head_stride, long long kv_batch_stride, long long kv_head_stride,
+                       int is_causal, int dtype, int kv8, void *workspace, long long workspace_bytes, void *hip_stream) {
   g_err[0] = 0;
   if (!q || !k || !v || !o || !workspace) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: null pointer");
   if (B < 1 || Hq < 1 || Hkv < 1 || Nq < 1 || Nk < 1 || D < 1) return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: sizes must be >= 1");
@@ -330,9 +348,9 @@ int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *l
   if (!fa_fwd_decode_supported(dtype, D, Hq, Hkv, Nq))
     return fail(FA_ERR_UNSUPPORTED, "fa_fwd_decode: needs f16 / bf16 / fp8_e4m3, D = 64 | 128 and (Hq / Hkv) * Nq <= 32 packed query rows; got dtype=%s D=%d "
                 "Hq=%d Hkv=%d Nq=%d (use fa_fwd_ex)", fa_dtype_name(dtype), D, Hq, Hkv, Nq);
-  const int dsm = dtype == FA_DTYPE_FP8_E4M3 ? 16 : 8;  // keeps every head 16-byte aligned
+  const int dsm = dtype == FA_DTYPE_FP8_E4M3 ? 16 : 8, ksm = kv8 ? 16 : dsm;  // keeps every head 16-byte aligned
   if (q_head_stride < (long long)Nq * D || kv_head_stride < (long long)Nk * D || (q_batch_stride % dsm) || (q_head_stride % dsm) ||
-      (kv_batch_stride % dsm) || (kv_head_stride % dsm) || q_batch_stride < 0 || kv_batch_stride < 0 ||
+      (kv_batch_stride % ksm) || (kv_head_stride % ksm) || q_batch_stride < 0 || kv_batch_stride < 0 ||
       (Hq > 1 && B > 1 && q_batch_stride < q_head_stride) || (Hkv > 1 && B > 1 && kv_batch_stride < kv_head_stride))
     return fail(FA_ERR_INVALID_ARG, "fa_fwd_decode: bad strides");
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)workspace) & 15)
@@ -347,8 +365,8 @@ int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *l
   p.B = B; p.Hq = Hq; p.Hkv = Hkv; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
   p.q_bs = q_batch_stride; p.q_hs = q_head_stride; p.kv_bs = kv_batch_stride; p.kv_hs = kv_head_stride;
   p.is_causal = is_causal ? 1 : 0;
-  p.S = fa::decode_splits(B, Hkv, Nk, D, dtype == FA_DTYPE_FP8_E4M3);
-  const hipError_t e = fa::launch_decode(p, D, dtype, (hipStream_t)hip_stream);
+  p.S = fa::decode_splits(B, Hkv, Nk, D, kv8);
+  const hipError_t e = fa::launch_decode(p, D, dtype, kv8, (hipStream_t)hip_stream);
   if (e != hipSuccess) return fail(FA_ERR_LAUNCH, "fa_fwd_decode: launch failed: %s", hipGetErrorString(e));
   return FA_OK;
 }

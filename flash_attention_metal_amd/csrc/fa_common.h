@@ -57,6 +57,7 @@ struct DecodeParams {
   long long q_bs, q_hs, kv_bs, kv_hs;  // elements
   int is_causal;
   int S;  // key splits per (batch, key head)
+  int q8 = 0;  // e4m3 K / V: the queries are e4m3 too (else 16-bit)
 };
 
 // dtype tags
@@ -81,7 +82,7 @@ hipError_t launch_fp8pv(const Params &p, int dtype, hipStream_t s);
 bool fp8pv_supported(int dtype, int D);
 hipError_t launch_splitkv(const Params &p, int dtype, hipStream_t s);
 
-hipError_t launch_decode(const DecodeParams &p, int D, int dtype, hipStream_t s);
+hipError_t launch_decode(const DecodeParams &p, int D, int dtype, int kv8, hipStream_t s);
 bool decode_supported(int dtype, int D);
 int decode_splits(int B, int Hkv, int Nk, int D, int kv8);  // kv8: e4m3 inputs (one LDS image per item: twice the items per CU)
 long long decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, int D);

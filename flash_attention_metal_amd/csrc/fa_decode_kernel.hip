@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64) void decode_partial_kernel(DecodeParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       u32x4 t = {0u, 0u, 0u, 0u};
-      if constexpr (KV8) {  // 8 e4m3 = 8 bytes, widened exactly
+      if (KV8 && p.q8) {  // e4m3 queries (8 bytes), widened exactly; else (an e4m3 KV cache under 16-bit queries) as the 16-bit path
         if (valid) {
           const u32x2 t8 = *reinterpret_cast<const u32x2 *>((const char *)p.q + qoff + 32 * ks + 8 * g);
           const unsigned w0 = t8[0], w1 = t8[1];
@@ -447,7 +447,11 @@ static hipError_t launch_decode_q(const DecodeParams &p, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_decode(const DecodeParams &p, int D, int dtype, hipStream_t s) {
+// dtype: of the queries (and of K / V unless kv8); kv8: K and V are e4m3 (dtype FP8: so are the queries; BF16: an e4m3 cache under
+// bf16 queries -- the arithmetic is bf16 either way)
+hipError_t launch_decode(const DecodeParams &p0, int D, int dtype, int kv8, hipStream_t s) {
+  DecodeParams p = p0;
+  p.q8 = (dtype == FA_DTYPE_FP8_E4M3);
   const int R = (p.Hq / p.Hkv) * p.Nq, QT = (R + 15) / 16;
   auto go = [&](auto tag) -> hipError_t {
     using Tag = decltype(tag);
@@ -455,7 +459,7 @@ hipError_t launch_decode(const DecodeParams &p, int D, int dtype, hipStream_t s)
     if (D == 128) return QT == 1 ? launch_decode_q<Tag, 128, 1>(p, s) : launch_decode_q<Tag, 128, 2>(p, s);
     return hipErrorInvalidValue;
   };
-  if (dtype == FA_DTYPE_FP8_E4M3) {  // e4m3 Q, K, V; bf16 arithmetic and output
+  if (kv8 || dtype == FA_DTYPE_FP8_E4M3) {  // e4m3 K, V (and Q, or bf16 Q); bf16 arithmetic and output
     if (D == 64) return QT == 1 ? launch_decode_q<BF16, 64, 1, true>(p, s) : launch_decode_q<BF16, 64, 2, true>(p, s);
     if (D == 128) return QT == 1 ? launch_decode_q<BF16, 128, 1, true>(p, s) : launch_decode_q<BF16, 128, 2, true>(p, s);
     return hipErrorInvalidValue;

@@ -199,8 +199,8 @@ def flash_attention_decode(
     stream: Optional[int] = None,
 ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Few query rows against a long key sequence (include/fa_mi355.h fa_fwd_decode): q [B,Hq,Nq,D], k/v [B,Hkv,Nk,D] with
-    (Hq / Hkv) * Nq <= 32, f16 / bf16, D = 64 | 128; the same operator as flash_attention_forward on these shapes, laid out for
-    the HBM roofline. `workspace`: a uint8 device tensor of at least decode_workspace_bytes(...) bytes (allocated here if None --
+    (Hq / Hkv) * Nq <= 32, f16 / bf16 / e4m3 -- or bf16 queries on an e4m3 k / v cache --, D = 64 | 128; the same operator as
+    flash_attention_forward on these shapes, laid out for the HBM roofline. `workspace`: a uint8 device tensor of at least decode_workspace_bytes(...) bytes (allocated here if None --
     the C entry point itself allocates nothing)."""
     lib = load_library()
     if q.dim() != 4 or k.dim() != 4 or k.shape != v.shape:
@@ -212,9 +212,10 @@ def flash_attention_decode(
     if not (q.is_cuda and k.is_cuda and v.is_cuda):
         raise RuntimeError("flash_attention_decode needs device tensors: there is no CPU path")
     fp8 = getattr(torch, "float8_e4m3fn", None)
-    if q.dtype not in (torch.float16, torch.bfloat16, fp8) or k.dtype != q.dtype or v.dtype != q.dtype:
-        raise ValueError(f"unsupported / mixed dtypes {q.dtype} {k.dtype} {v.dtype}")
-    odt = torch.bfloat16 if q.dtype == fp8 else q.dtype  # e4m3 inputs (an e4m3 KV cache): bf16 output, as in flash_attention_forward
+    kv8 = fp8 is not None and k.dtype == fp8 and v.dtype == fp8 and q.dtype == torch.bfloat16  # an e4m3 KV cache under bf16 queries (fa_fwd_decode_kv8)
+    if q.dtype not in (torch.float16, torch.bfloat16, fp8) or v.dtype != k.dtype or (k.dtype != q.dtype and not kv8):
+        raise ValueError(f"unsupported / mixed dtypes {q.dtype} {k.dtype} {v.dtype} (one of f16 / bf16 / e4m3, or bf16 queries on an e4m3 cache)")
+    odt = torch.bfloat16 if q.dtype == fp8 else q.dtype  # e4m3 inputs: bf16 output, as in flash_attention_forward
     qbs, qhs = _strides(q)
     kbs, khs = _strides(k)
     if _strides(v) != (kbs, khs):
@@ -237,9 +238,10 @@ def flash_attention_decode(
     if stream is None:
         stream = torch.cuda.current_stream(q.device).cuda_stream
     with torch.cuda.device(q.device):
-        st = lib.fa_fwd_decode(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
-                               B, Hq, Hkv, Nq, Nk, D, float(scale), qbs, qhs, kbs, khs, int(bool(is_causal)), _TORCH2FA[q.dtype],
-                               workspace.data_ptr(), workspace.numel(), stream)
+        entry = lib.fa_fwd_decode_kv8 if kv8 else lib.fa_fwd_decode
+        st = entry(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr() if lse is not None else None,
+                   B, Hq, Hkv, Nq, Nk, D, float(scale), qbs, qhs, kbs, khs, int(bool(is_causal)), _TORCH2FA[q.dtype],
+                   workspace.data_ptr(), workspace.numel(), stream)
     if st != 0:
         raise FaError(st, lib.fa_last_error().decode())
     return out, lse

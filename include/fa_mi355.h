@@ -180,6 +180,14 @@ int fa_fwd_decode(const void *q, const void *k, const void *v, void *o, float *l
                   long long q_batch_stride, long long q_head_stride,
                   long long kv_batch_stride, long long kv_head_stride,
                   int is_causal, int dtype, void *workspace, long long workspace_bytes, void *hip_stream);
+/* The same step on an e4m3 KV cache under 16-bit queries, the usual serving layout: k, v e4m3 (kv strides in elements, multiples of 16),
+ * q and o bf16 (q_dtype FA_DTYPE_BF16; FA_DTYPE_FP8_E4M3 makes this fa_fwd_decode with dtype e4m3). K and V are widened exactly to bf16
+ * on their way into LDS: the arithmetic and tolerances are those of the bf16 path on the widened cache. Same workspace. */
+int fa_fwd_decode_kv8(const void *q, const void *k, const void *v, void *o, float *lse,
+                      int B, int Hq, int Hkv, int Nq, int Nk, int D, float scale,
+                      long long q_batch_stride, long long q_head_stride,
+                      long long kv_batch_stride, long long kv_head_stride,
+                      int is_causal, int q_dtype, void *workspace, long long workspace_bytes, void *hip_stream);
 long long fa_fwd_decode_workspace_bytes(int B, int Hq, int Hkv, int Nq, int Nk, int D);
 int fa_fwd_decode_supported(int dtype, int D, int Hq, int Hkv, int Nq);
 

@@ -84,6 +84,20 @@ def test_decode_e4m3_inputs(fa, oracle_mod):
         o64, l64 = oracle_mod.attn_fwd_ex_f64(q, k, v, causal)
         assert np.abs(o8.float().cpu().numpy() - o64).max() < 2 * TOL_O["bf16"], what
         assert np.abs(l8.cpu().numpy() - l64).max() < lse_tol("bf16", 1, q, k), what
+    # bf16 queries on an e4m3 KV cache (fa_fwd_decode_kv8): the serving layout; same arithmetic as the bf16 path on the widened cache
+    for (B, Hq, Hkv, Nq, Nk, D, causal) in ((1, 32, 8, 1, 4096, 128, True), (2, 16, 4, 2, 1000, 64, True), (1, 8, 8, 4, 640, 64, False)):
+        q = oracle_mod.round_to(oracle_mod.init_random(B * Hq * Nq * D, 5).reshape(B, Hq, Nq, D), "bf16")
+        k = oracle_mod.round_to(2.0 * oracle_mod.init_random(B * Hkv * Nk * D, 6).reshape(B, Hkv, Nk, D), "fp8")
+        v = oracle_mod.round_to(2.0 * oracle_mod.init_random(B * Hkv * Nk * D, 7).reshape(B, Hkv, Nk, D), "fp8")
+        o8, l8 = fa.flash_attention_decode(to_dev(q, "bf16"), to_dev(k, "fp8"), to_dev(v, "fp8"), is_causal=causal)
+        ob, lb = fa.flash_attention_decode(to_dev(q, "bf16"), to_dev(k, "bf16"), to_dev(v, "bf16"), is_causal=causal)
+        torch.cuda.synchronize()
+        assert o8.dtype == torch.bfloat16 and (o8.float() - ob.float()).abs().max().item() < TOL_O["bf16"] and (l8 - lb).abs().max().item() < 2e-5
+        o64, l64 = oracle_mod.attn_fwd_ex_f64(q, k, v, causal)
+        assert np.abs(o8.float().cpu().numpy() - o64).max() < 2 * TOL_O["bf16"]
+        assert np.abs(l8.cpu().numpy() - l64).max() < lse_tol("bf16", 1, q, k)
+    with pytest.raises(ValueError):  # f16 queries on an e4m3 cache: not offered (the arithmetic is bf16)
+        fa.flash_attention_decode(to_dev(q, "f16"), to_dev(k, "fp8"), to_dev(v, "fp8"))
     # dtypes must agree; strides of an e4m3 tensor are multiples of 16
     x = torch.zeros(1, 8, 1, 64, dtype=torch.float8_e4m3fn, device="cuda")
     kv = torch.zeros(1, 8, 200, 64, dtype=torch.bfloat16, device="cuda")
