@@ -1,6 +1,6 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests_full.log 2>&1 || { tail -40 gpurun_out/gpu_tests_full.log; exit 1; }
-tail -2 gpurun_out/gpu_tests_full.log
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+L=flash_attention_metal_amd/csrc/libfa_mi355.so
+timeout -k 10 1000 python tools/ab.py $L:10 tools/ab/lib_d128_k2.so:10 tools/ab/lib_d128_k4.so:10 tools/ab/lib_d128_v2.so:10 tools/ab/lib_d128_v4.so:10 --shapes c4,d128c4k --rounds 6 --iters 6 --warm-ms 600 > gpurun_out/ab_d128_knobs_warm.log 2>&1
+cat gpurun_out/ab_d128_knobs_warm.log
